@@ -1,0 +1,138 @@
+"""GPU parity: HIP matcher (through the C ABI) vs the CPU oracle — bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import matcher_oracle as mo
+from util_data import image_set
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_batch(desc, counts, pairs, **kw):
+    from vit_colmap_amd.matching import match_pairs, prepare_descriptors
+
+    n_images, n_max, d = desc.shape
+    prepared = prepare_descriptors(dev(desc), dev(counts))
+    m, c = match_pairs(prepared, dev(counts), n_images, n_max, d, dev(pairs), **kw)
+    torch.cuda.synchronize()
+    return m.cpu().numpy().view(np.uint32), c.cpu().numpy()
+
+
+def assert_batch_equal(desc, counts, pairs, **kw):
+    gm, gc = run_batch(desc, counts, pairs, **kw)
+    om, oc, _ = c_oracle.match_pairs(desc, counts, pairs, **kw)
+    assert np.array_equal(gc, oc), f"match counts differ: {np.nonzero(gc != oc)[0][:10]}"
+    for p in range(len(pairs)):
+        assert np.array_equal(gm[p, :gc[p]], om[p, :oc[p]]), f"pair {p} {pairs[p]}"
+    return gc
+
+
+def test_theta_table_exhaustive():
+    """Every possible angle input: GPU == oracle, so accept() agrees for all integer inputs."""
+    from vit_colmap_amd.matching import theta_table
+
+    n = mo.S_SAT + 4
+    g = theta_table(n).cpu().numpy()
+    o = mo.theta_f32(np.arange(n))
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+
+
+@pytest.mark.parametrize("n1,n2,d", [(512, 512, 384), (300, 300, 128), (33, 65, 128), (1, 7, 64),
+                                     (257, 31, 256), (640, 1000, 96), (2048, 2048, 256), (100, 50, 768),
+                                     (64, 64, 1024), (45, 77, 40)])
+@pytest.mark.parametrize("kind", ["scene", "full"])
+def test_knn_top2_matches_oracle(n1, n2, d, kind):
+    from vit_colmap_amd.matching import knn_top2
+
+    desc, _ = image_set(n1 * 7 + n2 + d, 2, max(n1, n2), d, kind=kind)
+    a, b = desc[0, :n1].copy(), desc[1, :n2].copy()
+    a[n1 // 2] = a[0]                                  # duplicate row
+    if n2 > 3:
+        b[n2 - 1] = b[1]                               # duplicate column -> tie on the best value
+    idx, best, second = [t.cpu().numpy() for t in knn_top2(dev(a), dev(b))]
+    o = c_oracle.top2_both(a, b)
+    assert np.array_equal(best, o[1])
+    assert np.array_equal(second, o[2])
+    assert np.array_equal(idx, o[0])
+
+
+def test_knn_top2_then_mutual_ratio_equals_oracle():
+    from vit_colmap_amd.matching import knn_top2, mutual_ratio
+
+    desc, _ = image_set(11, 2, 400, 128, kind="scene", noise=0.1)
+    a, b = desc[0, :400].copy(), desc[1, :333].copy()
+    r12 = knn_top2(dev(a), dev(b))
+    r21 = knn_top2(dev(b), dev(a))
+    for cc in (True, False):
+        out, cnt = mutual_ratio(r12, r21, 400, 333, cross_check=cc)
+        n = int(cnt.item())
+        ref = mo.match_pair(a, b, cross_check=cc)
+        assert n == len(ref) and n > 20
+        assert np.array_equal(out[:n].cpu().numpy().view(np.uint32), ref)
+
+
+@pytest.mark.parametrize("kind,d", [("scene", 384), ("vit", 384), ("full", 128), ("scene", 256)])
+def test_match_pairs_batch_exact(kind, d):
+    n_images, n_max = 10, 512
+    desc, counts = image_set(5, n_images, n_max, d, kind=kind)
+    pairs = mo.exhaustive_pairs(n_images)
+    gc = assert_batch_equal(desc, counts, pairs)
+    if kind == "scene":
+        assert gc.sum() > 1000            # the accept path is really exercised
+    if kind == "full":
+        assert gc.sum() == 0              # saturated similarities are all rejected
+
+
+def test_match_pairs_ragged_counts_and_empty_images():
+    n_images, n_max, d = 9, 300, 128
+    counts = np.array([300, 0, 1, 31, 32, 33, 257, 299, 64], np.int32)
+    desc, counts = image_set(6, n_images, n_max, d, kind="scene", counts=counts, noise=0.1)
+    pairs = mo.exhaustive_pairs(n_images)
+    gc = assert_batch_equal(desc, counts, pairs)
+    assert gc.sum() > 100
+    assert_batch_equal(desc, counts, pairs, cross_check=False)
+    assert_batch_equal(desc, counts, pairs, max_ratio=0.95, max_distance=1.2)
+
+
+def test_match_pairs_max_size_and_order_of_pairs():
+    n_images, n_max, d = 3, 2048, 256
+    desc, counts = image_set(7, n_images, n_max, d, kind="scene", noise=0.15)
+    pairs = np.array([[2, 0], [0, 1], [1, 1], [1, 2]], np.int32)   # arbitrary order, self pair
+    assert_batch_equal(desc, counts, pairs)
+
+
+def test_identical_images_give_identity_matches():
+    desc, counts = image_set(8, 1, 512, 384, kind="scene")
+    desc = np.concatenate([desc, desc], axis=0)
+    counts = np.concatenate([counts, counts])
+    gm, gc = run_batch(desc, counts, np.array([[0, 1]], np.int32))
+    m = gm[0, :gc[0]]
+    assert np.array_equal(m[:, 0], m[:, 1]) and gc[0] > 400
+
+
+def test_full_size_checksum_properties_c3():
+    """BASELINE config 3 size (50 images, 512 x 384, 1225 pairs): size-independent properties
+    plus an exact comparison of every pair (the C oracle does all 1225 in seconds)."""
+    n_images, n_max, d = 50, 512, 384
+    desc, counts = image_set(9, n_images, n_max, d, kind="scene")
+    pairs = mo.exhaustive_pairs(n_images)
+    gm, gc = run_batch(desc, counts, pairs)
+    # symmetry: matching (b, a) gives the transposed match list
+    gm2, gc2 = run_batch(desc, counts, np.ascontiguousarray(pairs[:, ::-1]))
+    for p in range(0, len(pairs), 37):
+        m = gm[p, :gc[p]]
+        mt = gm2[p, :gc2[p]]
+        assert gc[p] == gc2[p]
+        assert np.array_equal(m[np.argsort(m[:, 1], kind="stable")][:, ::-1], mt)
+        assert np.all(np.diff(m[:, 0].astype(np.int64)) > 0)          # sorted, no duplicate rows
+        assert len(np.unique(m[:, 1])) == len(m)                      # one-to-one
+    om, oc, _ = c_oracle.match_pairs(desc, counts, pairs)
+    assert np.array_equal(gc, oc)
+    for p in range(len(pairs)):
+        assert np.array_equal(gm[p, :gc[p]], om[p, :oc[p]])

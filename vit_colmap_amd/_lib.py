@@ -1,0 +1,80 @@
+"""ctypes binding of libvitcolmap_hip.so (C ABI declared in include/vitcolmap_hip.h).
+
+The library is the product path.  There is no CPU fallback: if the shared object is missing or
+a call fails, these functions raise.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitcolmap_hip.so")
+
+VC_OK = 0
+VC_MAX_KEYPOINTS = 2048
+VC_MAX_DESC_DIM = 1024
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_u8p, _i32p, _u32p, _f32p = POINTER(c_uint8), POINTER(c_int32), POINTER(c_uint32), POINTER(ctypes.c_float)
+
+# name -> (restype, argtypes); the single source the loader and tests/test_abi.py share
+SIGNATURES = {
+    "vc_abi_version": (c_int, []),
+    "vc_status_string": (c_char_p, [c_int]),
+    "vc_last_hip_error": (c_int, []),
+    "vc_prepared_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vc_prepare_descriptors": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vc_match_pairs_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float,
+                                  c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "vc_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vc_knn_top2_u8": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
+    "vc_mutual_ratio": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "vc_theta_table": (c_int, [c_void_p, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object once and attach signatures.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C vit_colmap_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vc_abi_version() != 1:
+        raise HipLibraryError(f"ABI version {lib.vc_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != VC_OK:
+        lib = load()
+        msg = lib.vc_status_string(status).decode()
+        raise HipLibraryError(f"{what}: {msg} (status {status}, hip error {lib.vc_last_hip_error()})")
+
+
+def stream_ptr(stream=None):
+    import torch
+
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return c_void_p(s.cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
