@@ -133,46 +133,133 @@ __global__ void prepare_kernel(const uint8_t* __restrict__ desc, const int32_t* 
 // ---------------------------------------------------------------------------------------
 // The pair kernel
 // ---------------------------------------------------------------------------------------
-struct ColState {  // per column of image B, in LDS
-  int best, second, idx;
-};
+// One workgroup (8 waves, 2 per SIMD) per image pair (a, b).
+//   * wave w keeps RT 32-row tiles of image a as MFMA A-fragments in registers for a pass
+//     (RT = 2: 8 x 64 = 512 rows per pass, so a 512-keypoint image needs ONE pass over b);
+//   * image b streams through an LDS ring of NS tile slots (12 KiB per slot at D = 384),
+//     one wave issuing the 1 KiB global_load_lds pieces of a whole tile, PF = NS-1 tiles
+//     ahead; the only in-loop synchronisation is one raw s_barrier per tile and a
+//     vmcnt(0) in the wave whose tile is due (no wave has more than one tile in flight);
+//   * per-row top-2 lives in registers as packed keys, per-column top-2 is merged across
+//     waves with two LDS atomics per lane and tile (order independent, see col_merge).
+//
+// Dynamic LDS: [ring NS x KS KiB][colbest u64 x n_pad][colsecond u32 x n_pad]
+//              [cterm i32 x n_pad][m21 i32 x n_pad][rbest, rsecond, ridx i32 x n_pad]
+//              [crow6 i32 x 8 waves x 64 rows][8 ints]
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kMaxSlots = 8;  // PF <= 7 keeps "one tile in flight per wave" true for 8 waves
 
-template <int KS>
-struct Smem {
-  alignas(16) uint8_t ring[2][KS * kFragBytes];  // B tiles, fragment-major (glds destination)
-  uint2 part[2][kWaves][kTile];                  // per-wave column partials of one tile
-  int cterm[kMaxN];                              // 128 * rowsum_b[j]
-  ColState col[kMaxN];
-  int rbest[kMaxN], rsecond[kMaxN], ridx[kMaxN];  // row results (image A)
-  int m21[kMaxN];
-  int wave_count[kWaves];
-};
+__host__ __device__ inline size_t lds_fixed_bytes(int n_pad) {
+  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + 64;
+}
+// number of ring slots for this problem size (0 = does not fit)
+inline int plan_slots(int ks, int n_pad) {
+  const long avail = (long)kLdsBytes - (long)lds_fixed_bytes(n_pad);
+  long ns = avail / ((long)ks * kFragBytes);
+  if (ns > kMaxSlots) ns = kMaxSlots;
+  return ns >= 2 ? (int)ns : 0;
+}
 
-// Issue the global->LDS copy of B tile `jt` into ring slot `slot`; fragments are dealt
-// round-robin to the waves.  The destination is wave-uniform base + lane*16 (LDS-DMA rule).
+__device__ inline void wg_barrier() {
+  // LDS writes/atomics of this wave are complete before it arrives; LDS-DMA stays in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Issue the global->LDS copy of one B tile (KS pieces of 1 KiB) from the calling wave.
+// The destination is wave-uniform base + lane*16 (LDS-DMA rule); the source is coalesced.
 template <int KS>
-__device__ inline void stage_tile(const uint8_t* __restrict__ b_frags, int jt, uint8_t* slot,
-                                  int wave, int lane) {
-  const uint8_t* src = b_frags + (size_t)jt * KS * kFragBytes;
+__device__ inline void stage_tile(const uint8_t* __restrict__ tile_src, uint8_t* slot, int lane) {
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
-    if ((kk % kWaves) == wave) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + kk * kFragBytes + lane * 16),
-          (__attribute__((address_space(3))) void*)(slot + kk * kFragBytes), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(tile_src + kk * kFragBytes + lane * 16),
+        (__attribute__((address_space(3))) void*)(slot + kk * kFragBytes), 16, 0, 0);
+  }
+}
+
+// Similarity tiles of NRT row tiles against one column tile + all top-2 updates.
+//
+// Exact int32 arithmetic on biased bytes: with a' = a-128, b' = b-128,
+//   s = sum a'b' + 128*ra + 128*rb - 16384*D.
+// The accumulator starts at the column term ct = 128*rb[j] + 32640*D, so after the K loop
+//   acc = s - rterm[i],  rterm[i] = 128*ra[i] - 49024*D,  and 0 <= acc <= 65025*D < 2^26.
+// Row search (fixed i): rterm is constant, so acc orders the columns -> key = acc<<6 | code.
+// Column search (fixed j): needs s itself -> key = (acc<<6) + crow6[i], where
+//   crow6[i] = (rterm[i] << 6) + code(i) is read from LDS while the MFMAs run.
+template <int KS, int RT, int NRT, bool FUSED>
+__device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&rbest)[RT][16],
+                                             u32 (&rsec)[RT][16], const uint8_t* slot,
+                                             const int* crow6_wave, int lane, int h, int ct, u32 jcode,
+                                             u32& cb, u32& cs2) {
+  v16i acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = ct;
+  // K loop in groups of G fragments, the next group's LDS reads issued ahead of this group's
+  // MFMAs; sched_barrier keeps the compiler from hoisting every read to the top (which costs
+  // 4*KS registers and spills).
+  constexpr int G = KS < 4 ? KS : 4;
+  constexpr int NG = KS / G;
+  static_assert(KS % G == 0, "KS must be a multiple of the fragment group");
+  const uint8_t* src = slot + lane * 16;
+  v4i bf[2][G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) bf[(g + 1) & 1][i] = *(const v4i*)(src + ((g + 1) * G + i) * kFragBytes);
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][g * G + i], bf[g & 1][i], acc[rt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    v4i cr[4];
+    if (FUSED) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cr[q] = *(const v4i*)(crow6_wave + rt * kTile + 8 * q + 4 * h);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const u32 a = (u32)acc[rt][r];
+      const u32 rk = (a << 6) | jcode;
+      rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
+      rbest[rt][r] = umax(rbest[rt][r], rk);
+      if (FUSED) {
+        const u32 ck = (a << 6) + (u32)cr[r >> 2][r & 3];
+        cs2 = umed3(cb, cs2, ck);
+        cb = umax(cb, ck);
+      }
     }
   }
 }
 
-template <int KS, bool FUSED>
+template <int KS, int RT, bool FUSED>
 __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
     const int32_t* __restrict__ pairs, float max_ratio, float max_distance, int cross_check,
-    int n_max, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts,
+    int n_max, int ns, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts,
     // !FUSED: one-way outputs (rows of A against B)
     int32_t* __restrict__ o_idx, int32_t* __restrict__ o_best, int32_t* __restrict__ o_second) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  Smem<KS>& sm = *reinterpret_cast<Smem<KS>*>(smem_raw);
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int n_pad = n_tiles_img * kTile;
+  uint8_t* ring = smem;
+  unsigned long long* colbest = (unsigned long long*)(smem + (size_t)ns * KS * kFragBytes);
+  u32* colsecond = (u32*)(colbest + n_pad);
+  int* cterm = (int*)(colsecond + n_pad);
+  int* m21 = cterm + n_pad;
+  int* rbest_s = m21 + n_pad;
+  int* rsecond_s = rbest_s + n_pad;
+  int* ridx_s = rsecond_s + n_pad;
+  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: column-search row constants
+  int* wave_count = crow6 + kWaves * 64;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -189,149 +276,139 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   const int32_t* a_rowsum = (const int32_t*)(a_frags + (size_t)n_tiles_img * KS * kFragBytes);
   const int32_t* b_rowsum = (const int32_t*)(b_frags + (size_t)n_tiles_img * KS * kFragBytes);
 
-  const int n_ct = ceil_div(n2, kTile);          // column tiles of B that hold valid rows
-  const int n_pass = ceil_div(n1, kPassRows);
+  constexpr int kRowsPerPass = kWaves * RT * kTile;
+  const int n_ct = ceil_div(n2, kTile);  // column tiles of b that hold valid rows
+  const int n_pass = ceil_div(n1, kRowsPerPass);
+  const int total = n_pass * n_ct;       // tiles consumed, in order (pass, jt)
+  const int pf = ns - 1;
+
+  if (total == 0) {  // an empty image: nothing can match (uniform exit)
+    if (FUSED) { if (tid == 0) out_counts[p] = 0; }
+    else for (int i = tid; i < n1; i += kThreads) { o_idx[i] = -1; o_best[i] = 0; o_second[i] = 0; }
+    return;
+  }
 
   // ---- per-pair LDS state ----------------------------------------------------------------
   for (int j = tid; j < n_ct * kTile; j += kThreads) {
-    sm.cterm[j] = 128 * b_rowsum[j];
-    sm.col[j].best = 0;
-    sm.col[j].second = 0;
-    sm.col[j].idx = -1;
+    cterm[j] = 128 * b_rowsum[j] + 32640 * d;
+    colbest[j] = 0ull;
+    colsecond[j] = 0u;
   }
-  if (n_ct > 0) stage_tile<KS>(b_frags, 0, sm.ring[0], wave, lane);
-  const int bias = -16384 * d;
+  const int rbias = -49024 * d;
+  int* crow6_wave = crow6 + wave * 64;
+
+  // producer / consumer cursors over the tile sequence
+  int prod_seq = 0, prod_jt = 0, prod_slot = 0;
+  for (; prod_seq < pf && prod_seq < total; ++prod_seq) {
+    if (wave == (prod_seq & (kWaves - 1)))
+      stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring + (size_t)prod_slot * KS * kFragBytes, lane);
+    if (++prod_jt == n_ct) prod_jt = 0;
+    if (++prod_slot == ns) prod_slot = 0;
+  }
+  int cons_seq = 0, cons_slot = 0;
 
   for (int pass = 0; pass < n_pass; ++pass) {
-    const int row_tile = pass * kWaves + wave;           // 32-row tile of A owned by this wave
-    const bool tile_valid = row_tile * kTile < n1;       // wave-uniform
-    // A fragments stay in registers for the whole pass
-    v4i afrag[KS];
+    const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
+    // number of this wave's row tiles that exist in the prepared buffer (wave-uniform)
+    const int nrt = min(max(n_tiles_img - tile0, 0), RT);
+    v4i afrag[RT][KS];
+    u32 rbest[RT][16], rsec[RT][16];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      afrag[kk] = tile_valid ? *(const v4i*)(a_frags + ((size_t)row_tile * KS + kk) * kFragBytes + lane * 16)
-                             : v4i{0, 0, 0, 0};
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool ex = rt < nrt;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+        afrag[rt][kk] = ex ? *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16)
+                           : v4i{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
     }
-    // accumulator start values: 128*rowsum_a[row] - 16384*D for the 16 rows of this lane
-    int rinit[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-      rinit[r] = tile_valid ? 128 * a_rowsum[row_tile * kTile + lrow] + bias : 0;
+    // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows)
+    int my_rterm = 0;
+    if (lane < nrt * kTile) my_rterm = 128 * a_rowsum[tile0 * kTile + lane] + rbias;
+    if (FUSED && lane < RT * kTile) {
+      const int o = lane & 31;
+      const int code = 63 - ((lane & 32) + (o - 4 * ((o >> 2) & 1)));  // row code without the half-wave offset
+      crow6_wave[lane] = (int)(((u32)my_rterm << 6) + (u32)code);
     }
-    u32 rbest[16], rsec[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { rbest[r] = 0; rsec[r] = 0; }
 
-    for (int jt = 0; jt < n_ct; ++jt) {
-      __syncthreads();  // tile jt landed (vmcnt(0) + barrier); everyone is done with tile jt-1
-      // next tile (wraps to tile 0 for the next pass)
-      {
-        const int nxt = (jt + 1 < n_ct) ? jt + 1 : 0;
-        const bool more = (jt + 1 < n_ct) || (pass + 1 < n_pass);
-        const int seq = pass * n_ct + jt + 1;
-        if (more) stage_tile<KS>(b_frags, nxt, sm.ring[seq & 1], wave, lane);
-      }
-      const int seq = pass * n_ct + jt;
-      // column partials of the previous tile are complete: one wave folds them into sm.col
-      if (FUSED && seq > 0 && wave == ((seq - 1) % kWaves) && lane < kTile) {
-        const int pseq = seq - 1;
-        const int pjt = pseq % n_ct, ppass = pseq / n_ct;
-        ColState cs = sm.col[pjt * kTile + lane];
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          const uint2 pr = sm.part[pseq & 1][w][lane];
-          const int sb = (int)(pr.x >> 6), ss = (int)(pr.y >> 6);
-          const int row = ppass * kPassRows + w * kTile + (63 - (int)(pr.x & 63));
-          if (sb > cs.best) { cs.second = max(cs.best, ss); cs.best = sb; cs.idx = row; }
-          else { cs.second = max(cs.second, sb); }
-        }
-        sm.col[pjt * kTile + lane] = cs;
+    for (int jt = 0; jt < n_ct; ++jt, ++cons_seq) {
+      // tile cons_seq was issued by wave cons_seq % 8, which has nothing younger in flight
+      if (wave == (cons_seq & (kWaves - 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wg_barrier();
+      // the slot consumed in the previous iteration is free: refill it PF tiles ahead
+      if (prod_seq < total) {
+        if (wave == (prod_seq & (kWaves - 1)))
+          stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring + (size_t)prod_slot * KS * kFragBytes, lane);
+        ++prod_seq;
+        if (++prod_jt == n_ct) prod_jt = 0;
+        if (++prod_slot == ns) prod_slot = 0;
       }
 
-      const uint8_t* slot = sm.ring[seq & 1];
-      const int ct = sm.cterm[jt * kTile + c];
-      v16i acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = rinit[r] + ct;
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        const v4i bfrag = *(const v4i*)(slot + kk * kFragBytes + lane * 16);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[kk], bfrag, acc, 0, 0, 0);
-      }
-      // top-2 updates
+      const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
+      if (++cons_slot == ns) cons_slot = 0;
+      const int ct = cterm[jt * kTile + c];
       const u32 jcode = 63u - (u32)jt;
       u32 cb = 0, cs2 = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const u32 t = tile_valid ? (u32)acc[r] : 0u;
-        const u32 rk = (t << 6) | jcode;
-        rsec[r] = umed3(rbest[r], rsec[r], rk);
-        rbest[r] = umax(rbest[r], rk);
-        if (FUSED) {
-          const u32 ck = (t << 6) | (u32)(63 - ((r & 3) + 8 * (r >> 2)));
-          cs2 = umed3(cb, cs2, ck);
-          cb = umax(cb, ck);
-        }
-      }
-      if (FUSED) {
-        // rows of the upper half-wave are 4 further down: make the codes comparable
-        cb -= 4u * h;
-        cs2 -= 4u * h;
-        const u32 ob = (u32)__shfl_xor((int)cb, 32), os = (u32)__shfl_xor((int)cs2, 32);
-        const u32 nb = umax(cb, ob);
-        const u32 ns = umax(umin(cb, ob), umax(cs2, os));
-        if (h == 0) sm.part[seq & 1][wave][c] = make_uint2(nb, ns);
+      if (nrt == RT) process_tile<KS, RT, RT, FUSED>(afrag, rbest, rsec, slot, crow6_wave, lane, h, ct, jcode, cb, cs2);
+      else if (RT > 1 && nrt == 1) process_tile<KS, RT, 1, FUSED>(afrag, rbest, rsec, slot, crow6_wave, lane, h, ct, jcode, cb, cs2);
+
+      if (FUSED && nrt > 0) {
+        // col_merge: this lane's best / second over its rows of column j -> LDS, any order.
+        //   best64  = max over keys (s << 32 | ~row): highest s, lowest row on ties
+        //   second  = max over { every lane's second } U { every best that is not THE best }:
+        //             a best that loses its max contributes itself, one that wins contributes
+        //             the value it displaced.
+        const int j = jt * kTile + c;
+        const u32 sb = cb >> 6;
+        const u32 grow = (u32)(tile0 * kTile) + (63u - (cb & 63u)) + 4u * h;
+        const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
+        const unsigned long long old = atomicMax(&colbest[j], key);
+        u32 cand = key > old ? (u32)(old >> 32) : sb;
+        cand = umax(cand, cs2 >> 6);
+        atomicMax(&colsecond[j], cand);
       }
     }  // column tiles
 
     // ---- row results of this pass: reduce over the 32 lanes that share a row ------------
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const u32 m = half_max(rbest[r]);
-      const unsigned long long eq = __ballot(rbest[r] == m);
-      const int win = h ? __builtin_ctz((u32)(eq >> 32)) : __builtin_ctz((u32)eq);  // lowest column wins
-      const u32 x = (c == win) ? rsec[r] : rbest[r];
-      const u32 s2 = half_max(x);
-      if (c == 0) {
-        const int row = row_tile * kTile + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < n1) {
-          const int sb = (int)(m >> 6);
-          const int idx = sb > 0 ? (63 - (int)(m & 63)) * kTile + win : -1;
-          const int s2v = sb > 0 ? (int)(s2 >> 6) : 0;
-          if (FUSED) { sm.rbest[row] = sb; sm.rsecond[row] = s2v; sm.ridx[row] = idx; }
-          else { o_idx[row] = idx; o_best[row] = sb; o_second[row] = s2v; }
+    for (int rt = 0; rt < RT; ++rt) {
+      if (rt < nrt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const u32 m = half_max(rbest[rt][r]);
+          const unsigned long long eq = __ballot(rbest[rt][r] == m);
+          const int win = h ? __builtin_ctz((u32)(eq >> 32)) : __builtin_ctz((u32)eq);  // lowest column
+          const u32 x = (c == win) ? rsec[rt][r] : rbest[rt][r];
+          const u32 s2 = half_max(x);
+          // this row's term lives in lane (rt*32 + local row) of the wave
+          const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int rterm = __shfl(my_rterm, rt * kTile + lrow);
+          if (c == 0) {
+            const int row = (tile0 + rt) * kTile + lrow;
+            if (row < n1) {
+              const int sb = (int)(m >> 6) + rterm;
+              const int idx = sb > 0 ? (63 - (int)(m & 63)) * kTile + win : -1;
+              const int s2v = sb > 0 ? (int)(s2 >> 6) + rterm : 0;
+              if (FUSED) { rbest_s[row] = sb; rsecond_s[row] = s2v; ridx_s[row] = idx; }
+              else { o_idx[row] = idx; o_best[row] = sb; o_second[row] = s2v; }
+            }
+          }
         }
       }
     }
   }  // passes
 
   if (!FUSED) return;
-
-  // ---- fold the last tile's column partials ---------------------------------------------
-  __syncthreads();
-  const int total = n_pass * n_ct;
-  if (total > 0 && wave == 0 && lane < kTile) {
-    const int pseq = total - 1;
-    const int pjt = pseq % n_ct, ppass = pseq / n_ct;
-    ColState cs = sm.col[pjt * kTile + lane];
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      const uint2 pr = sm.part[pseq & 1][w][lane];
-      const int sb = (int)(pr.x >> 6), ss = (int)(pr.y >> 6);
-      const int row = ppass * kPassRows + w * kTile + (63 - (int)(pr.x & 63));
-      if (sb > cs.best) { cs.second = max(cs.best, ss); cs.best = sb; cs.idx = row; }
-      else { cs.second = max(cs.second, sb); }
-    }
-    sm.col[pjt * kTile + lane] = cs;
-  }
   __syncthreads();
 
   // ---- angle + ratio tests, cross check, ordered compaction -----------------------------
   if (cross_check) {
     for (int j = tid; j < n2; j += kThreads) {
-      const ColState cs = sm.col[j];
-      sm.m21[j] = accept_dev(cs.best, cs.second, max_ratio, max_distance) ? cs.idx : -1;
+      const unsigned long long kb = colbest[j];
+      const int sb = (int)(kb >> 32);
+      const int row = (int)(0xFFFFFFFFu - (u32)kb);
+      m21[j] = accept_dev(sb, (int)colsecond[j], max_ratio, max_distance) ? row : -1;
     }
   }
   __syncthreads();
@@ -342,17 +419,17 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     bool ok = false;
     int j = -1;
     if (i < n1) {
-      j = sm.ridx[i];
-      ok = accept_dev(sm.rbest[i], sm.rsecond[i], max_ratio, max_distance);
-      if (ok && cross_check) ok = (sm.m21[j] == i);
+      j = ridx_s[i];
+      ok = accept_dev(rbest_s[i], rsecond_s[i], max_ratio, max_distance);
+      if (ok && cross_check) ok = (m21[j] == i);
     }
     const unsigned long long mask = __ballot(ok);
-    if (lane == 0) sm.wave_count[wave] = __popcll(mask);
+    if (lane == 0) wave_count[wave] = __popcll(mask);
     __syncthreads();
     int before = base;
-    for (int w = 0; w < wave; ++w) before += sm.wave_count[w];
+    for (int w = 0; w < wave; ++w) before += wave_count[w];
     int chunk_total = 0;
-    for (int w = 0; w < kWaves; ++w) chunk_total += sm.wave_count[w];
+    for (int w = 0; w < kWaves; ++w) chunk_total += wave_count[w];
     if (ok) {
       const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
       out[2 * pos] = (uint32_t)i;
@@ -425,37 +502,42 @@ inline int pick_ks(int d) {
   return -1;
 }
 
-template <int KS, bool FUSED>
+template <int KS, int RT, bool FUSED>
 int launch_pair(const void* prepared, const int32_t* counts, int n_tiles, int d, const int32_t* pairs,
                 int n_pairs, float max_ratio, float max_distance, int cross_check, int n_max,
                 uint32_t* out_matches, int32_t* out_counts, int32_t* o_idx, int32_t* o_best,
                 int32_t* o_second, hipStream_t stream) {
-  const size_t smem = sizeof(Smem<KS>);
-  static thread_local bool configured = false;  // per instantiation
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<KS, FUSED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int n_pad = n_tiles * kTile;
+  const int ns = plan_slots(KS, n_pad);
+  if (ns == 0) return VC_ERR_UNSUPPORTED;
+  const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes(n_pad);
+  static thread_local size_t configured = 0;  // per instantiation: largest size enabled so far
+  if (smem > configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<KS, RT, FUSED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) return vc::fail(e);
-    configured = true;
+    configured = kLdsBytes;
   }
-  hipLaunchKernelGGL((pair_kernel<KS, FUSED>), dim3(n_pairs), dim3(kThreads), smem, stream,
+  hipLaunchKernelGGL((pair_kernel<KS, RT, FUSED>), dim3(n_pairs), dim3(kThreads), smem, stream,
                      (const uint8_t*)prepared, counts, n_tiles, d, pairs, max_ratio, max_distance,
-                     cross_check, n_max, out_matches, out_counts, o_idx, o_best, o_second);
+                     cross_check, n_max, ns, out_matches, out_counts, o_idx, o_best, o_second);
   return vc::check_launch();
 }
 
+// RT = 2 (512 rows per pass) while its register budget holds (A fragments: 2*KS*4 VGPRs);
+// long descriptors fall back to one row tile per wave.
 template <bool FUSED>
 int dispatch_pair(int ks, const void* prepared, const int32_t* counts, int n_tiles, int d,
                   const int32_t* pairs, int n_pairs, float max_ratio, float max_distance,
                   int cross_check, int n_max, uint32_t* out_matches, int32_t* out_counts,
                   int32_t* o_idx, int32_t* o_best, int32_t* o_second, hipStream_t stream) {
-#define VC_CASE(K)                                                                              \
+#define VC_CASE(K, R)                                                                           \
   case K:                                                                                       \
-    return launch_pair<K, FUSED>(prepared, counts, n_tiles, d, pairs, n_pairs, max_ratio,       \
-                                 max_distance, cross_check, n_max, out_matches, out_counts,     \
-                                 o_idx, o_best, o_second, stream);
+    return launch_pair<K, R, FUSED>(prepared, counts, n_tiles, d, pairs, n_pairs, max_ratio,    \
+                                    max_distance, cross_check, n_max, out_matches, out_counts,  \
+                                    o_idx, o_best, o_second, stream);
   switch (ks) {
-    VC_CASE(2) VC_CASE(4) VC_CASE(8) VC_CASE(12) VC_CASE(16) VC_CASE(24) VC_CASE(32)
+    VC_CASE(2, 2) VC_CASE(4, 2) VC_CASE(8, 2) VC_CASE(12, 2) VC_CASE(16, 1) VC_CASE(24, 1) VC_CASE(32, 1)
     default: return VC_ERR_UNSUPPORTED;
   }
 #undef VC_CASE
