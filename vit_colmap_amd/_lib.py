@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitcolmap_hip.so")
+# VITCOLMAP_HIP_LIB: developer override used by tools/ to A/B experimental kernel builds
+LIB_PATH = os.environ.get("VITCOLMAP_HIP_LIB") or os.path.join(_HERE, "libvitcolmap_hip.so")
 
 VC_OK = 0
 VC_MAX_KEYPOINTS = 2048

@@ -40,7 +40,10 @@ constexpr int kMaxN = VC_MAX_KEYPOINTS;      // 2048 -> at most 64 column tiles 
 constexpr int kFragBytes = 1024;             // 64 lanes x 16 B
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-__host__ __device__ inline int tiles_of(int n_max) { return ceil_div(n_max, kTile); }
+// 32-row tiles per prepared image, rounded up to a whole pass of the pair kernel (8 waves x 2
+// row tiles) so that every tile index a workgroup touches exists; the extra tiles hold
+// neutral rows (all-zero descriptors: similarity 0 with everything).
+__host__ __device__ inline int tiles_of(int n_max) { return ceil_div(ceil_div(n_max, kTile), 16) * 16; }
 __host__ __device__ inline int ksteps_of(int d) { return ceil_div(d, 32); }
 __host__ __device__ inline size_t image_bytes(int n_tiles, int ks) {
   return (size_t)n_tiles * ks * kFragBytes + (size_t)n_tiles * kTile * sizeof(int32_t);
@@ -165,37 +168,59 @@ __device__ inline void wg_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Issue the global->LDS copy of one B tile (KS pieces of 1 KiB) from the calling wave.
-// The destination is wave-uniform base + lane*16 (LDS-DMA rule); the source is coalesced.
-template <int KS>
-__device__ inline void stage_tile(const uint8_t* __restrict__ tile_src, uint8_t* slot, int lane) {
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(tile_src + kk * kFragBytes + lane * 16),
-        (__attribute__((address_space(3))) void*)(slot + kk * kFragBytes), 16, 0, 0);
-  }
+// One 1 KiB LDS-DMA piece: 64 lanes x 16 B, global source per lane, LDS destination =
+// wave-uniform byte address `lds_dst` + lane*16.  Issued from inline asm on purpose: hipcc
+// treats the builtin form as an LDS write that may alias every later ds_read and inserts
+// s_waitcnt vmcnt(0) before the next LDS read of the issuing wave, which drains the prefetch
+// it has just started.  Hidden in asm, the copy is invisible to the compiler's counters; the
+// kernel waits for it by hand (vmcnt(0) in the issuing wave, then the workgroup barrier).
+__device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst) {
+  u32 keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
 }
 
-// Similarity tiles of NRT row tiles against one column tile + all top-2 updates.
+__device__ __forceinline__ u32 lds_addr(const void* p) {
+  return (u32)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// Issue the global->LDS copy of one B tile (KS pieces of 1 KiB) from the calling wave.
+template <int KS>
+__device__ inline void stage_tile(const uint8_t* __restrict__ tile_src, u32 slot_lds, int lane) {
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk)
+    glds16(tile_src + kk * kFragBytes + lane * 16, slot_lds + kk * kFragBytes);
+}
+
+// Similarity tiles of the wave's RT row tiles against one column tile + all top-2 updates.
 //
 // Exact int32 arithmetic on biased bytes: with a' = a-128, b' = b-128,
-//   s = sum a'b' + 128*ra + 128*rb - 16384*D.
-// The accumulator starts at the column term ct = 128*rb[j] + 32640*D, so after the K loop
-//   acc = s - rterm[i],  rterm[i] = 128*ra[i] - 49024*D,  and 0 <= acc <= 65025*D < 2^26.
-// Row search (fixed i): rterm is constant, so acc orders the columns -> key = acc<<6 | code.
-// Column search (fixed j): needs s itself -> key = (acc<<6) + crow6[i], where
-//   crow6[i] = (rterm[i] << 6) + code(i) is read from LDS while the MFMAs run.
-template <int KS, int RT, int NRT, bool FUSED>
+//   s = sum a'b' + 128*ra + 128*rb - 16384*D = acc + ct[j] + rterm[i],
+//   acc = sum a'b' (MFMA, C = 0),  ct[j] = 128*rb[j] + 32640*D,  rterm[i] = 128*ra[i] - 49024*D,
+// and u = acc + ct satisfies 0 <= u <= 65025*D < 2^26.
+// Row search (fixed i): rterm is constant, so u orders the columns:
+//   rk = (acc << 6) + ((ct << 6) + jcode)                       one v_lshl_add_u32
+// Column search (fixed j): needs s itself:
+//   ck = (s << 6) + code(i) = rk + crow6[i] - jcode              one v_add3_u32
+//   with crow6[i] = (rterm[i] << 6) + code(i) read from LDS while the MFMAs run.
+// Each search then costs v_med3_u32 + v_max_u32: 6 VALU instructions per similarity in all.
+template <int KS, int RT, bool FUSED>
 __device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&rbest)[RT][16],
                                              u32 (&rsec)[RT][16], const uint8_t* slot,
                                              const int* crow6_wave, int lane, int h, int ct, u32 jcode,
                                              u32& cb, u32& cs2) {
-  v16i acc[NRT];
+  v16i acc[RT];
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[rt][r] = ct;
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0;
   // K loop in groups of G fragments, the next group's LDS reads issued ahead of this group's
   // MFMAs; sched_barrier keeps the compiler from hoisting every read to the top (which costs
   // 4*KS registers and spills).
@@ -215,12 +240,24 @@ __device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&r
 #pragma unroll
     for (int i = 0; i < G; ++i)
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) {
+#ifdef VC_EXP_NO_MFMA
+        acc[rt][i] += afrag[rt][g * G + i][0] ^ bf[g & 1][i][1];
+#else
         acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][g * G + i], bf[g & 1][i], acc[rt], 0, 0, 0);
+#endif
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef VC_EXP_NO_EPILOGUE
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) asm volatile("" :: "v"(acc[rt]));
+  return;
+#endif
+  const u32 ctj = ((u32)ct << 6) + jcode;
+  const u32 negj = 0u - jcode;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
     v4i cr[4];
     if (FUSED) {
 #pragma unroll
@@ -228,12 +265,11 @@ __device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&r
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const u32 a = (u32)acc[rt][r];
-      const u32 rk = (a << 6) | jcode;
+      const u32 rk = ((u32)acc[rt][r] << 6) + ctj;
       rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
       rbest[rt][r] = umax(rbest[rt][r], rk);
       if (FUSED) {
-        const u32 ck = (a << 6) + (u32)cr[r >> 2][r & 3];
+        const u32 ck = rk + (u32)cr[r >> 2][r & 3] + negj;
         cs2 = umed3(cb, cs2, ck);
         cb = umax(cb, ck);
       }
@@ -296,12 +332,13 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   }
   const int rbias = -49024 * d;
   int* crow6_wave = crow6 + wave * 64;
+  const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
 
   // producer / consumer cursors over the tile sequence
   int prod_seq = 0, prod_jt = 0, prod_slot = 0;
   for (; prod_seq < pf && prod_seq < total; ++prod_seq) {
     if (wave == (prod_seq & (kWaves - 1)))
-      stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring + (size_t)prod_slot * KS * kFragBytes, lane);
+      stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring_lds + (u32)prod_slot * (KS * kFragBytes), lane);
     if (++prod_jt == n_ct) prod_jt = 0;
     if (++prod_slot == ns) prod_slot = 0;
   }
@@ -309,23 +346,20 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
 
   for (int pass = 0; pass < n_pass; ++pass) {
     const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
-    // number of this wave's row tiles that exist in the prepared buffer (wave-uniform)
-    const int nrt = min(max(n_tiles_img - tile0, 0), RT);
+    // A fragments stay in registers for the whole pass (every tile index exists: tiles_of()).
     v4i afrag[RT][KS];
     u32 rbest[RT][16], rsec[RT][16];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const bool ex = rt < nrt;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk)
-        afrag[rt][kk] = ex ? *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16)
-                           : v4i{0, 0, 0, 0};
+        afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
     }
     // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows)
-    int my_rterm = 0;
-    if (lane < nrt * kTile) my_rterm = 128 * a_rowsum[tile0 * kTile + lane] + rbias;
+    int my_rterm = rbias;
+    if (lane < RT * kTile) my_rterm = 128 * a_rowsum[tile0 * kTile + lane] + rbias;
     if (FUSED && lane < RT * kTile) {
       const int o = lane & 31;
       const int code = 63 - ((lane & 32) + (o - 4 * ((o >> 2) & 1)));  // row code without the half-wave offset
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
       // the slot consumed in the previous iteration is free: refill it PF tiles ahead
       if (prod_seq < total) {
         if (wave == (prod_seq & (kWaves - 1)))
-          stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring + (size_t)prod_slot * KS * kFragBytes, lane);
+          stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring_lds + (u32)prod_slot * (KS * kFragBytes), lane);
         ++prod_seq;
         if (++prod_jt == n_ct) prod_jt = 0;
         if (++prod_slot == ns) prod_slot = 0;
@@ -350,10 +384,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
       const int ct = cterm[jt * kTile + c];
       const u32 jcode = 63u - (u32)jt;
       u32 cb = 0, cs2 = 0;
-      if (nrt == RT) process_tile<KS, RT, RT, FUSED>(afrag, rbest, rsec, slot, crow6_wave, lane, h, ct, jcode, cb, cs2);
-      else if (RT > 1 && nrt == 1) process_tile<KS, RT, 1, FUSED>(afrag, rbest, rsec, slot, crow6_wave, lane, h, ct, jcode, cb, cs2);
+      process_tile<KS, RT, FUSED>(afrag, rbest, rsec, slot, crow6_wave, lane, h, ct, jcode, cb, cs2);
 
-      if (FUSED && nrt > 0) {
+#ifndef VC_EXP_NO_COLATOMIC
+      if (FUSED) {
         // col_merge: this lane's best / second over its rows of column j -> LDS, any order.
         //   best64  = max over keys (s << 32 | ~row): highest s, lowest row on ties
         //   second  = max over { every lane's second } U { every best that is not THE best }:
@@ -368,12 +402,22 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
         cand = umax(cand, cs2 >> 6);
         atomicMax(&colsecond[j], cand);
       }
+#else
+      asm volatile("" :: "v"(cb), "v"(cs2));
+#endif
     }  // column tiles
 
     // ---- row results of this pass: reduce over the 32 lanes that share a row ------------
+#ifdef VC_EXP_NO_ROWREDUCE
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(rbest[rt][r]), "v"(rsec[rt][r]));
+    if (false)
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      if (rt < nrt) {
+      {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const u32 m = half_max(rbest[rt][r]);
@@ -400,6 +444,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   }  // passes
 
   if (!FUSED) return;
+#ifdef VC_EXP_NO_FINALIZE
+  if (tid == 0) out_counts[p] = 0;
+  return;
+#endif
   __syncthreads();
 
   // ---- angle + ratio tests, cross check, ordered compaction -----------------------------
