@@ -20,10 +20,25 @@ def main():
     ap.add_argument("--d", type=int, default=384)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kind", default="vit")
+    ap.add_argument("--pairs", default="exhaustive", help="exhaustive | sameb | samea | sorted_b")
     a = ap.parse_args()
     desc, counts = image_set(1, a.images, a.n, a.d, kind=a.kind)
     dd, dc = torch.from_numpy(desc).cuda(), torch.from_numpy(counts).cuda()
     pairs = exhaustive_pairs(a.images, "cuda")
+    if a.pairs == "sameb":      # every pair streams the same image b: B is always L2-hot
+        pairs[:, 1] = 0
+    elif a.pairs == "samea":
+        pairs[:, 0] = 0
+    elif a.pairs == "sorted_b":  # concurrent workgroups of one XCD (block id % 8) share b
+        pn = pairs.cpu().numpy()
+        order = np.lexsort((pn[:, 0], pn[:, 1]))
+        pn = pn[order]
+        n = len(pn)
+        chunk = (n + 7) // 8
+        idx = np.arange(n)
+        src = (idx % 8) * chunk + idx // 8
+        src = np.minimum(src, n - 1)
+        pairs = torch.from_numpy(np.ascontiguousarray(pn[src])).cuda()
     P = pairs.shape[0]
     prepared = prepare_descriptors(dd, dc)
     m = torch.empty((P, a.n, 2), dtype=torch.int32, device="cuda")

@@ -148,12 +148,15 @@ __global__ void prepare_kernel(const uint8_t* __restrict__ desc, const int32_t* 
 //
 // Dynamic LDS: [ring NS x KS KiB][colbest u64 x n_pad][colsecond u32 x n_pad]
 //              [cterm i32 x n_pad][m21 i32 x n_pad][rbest, rsecond, ridx i32 x n_pad]
-//              [crow6 i32 x 8 waves x 64 rows][8 ints]
+//              [crow6 i32 x 8 waves x 64 rows][row-reduce scratch 8 waves x 4224 B][8 ints]
 constexpr int kLdsBytes = 160 * 1024;
+// end-of-pass row reduction: per wave 16 rows x (32 + 1 pad) entries of {best key, second key}
+constexpr int kRowScratchEntries = 16 * 33;
+constexpr int kRowScratchBytes = kRowScratchEntries * 8;
 constexpr int kMaxSlots = 8;  // PF <= 7 keeps "one tile in flight per wave" true for 8 waves
 
 __host__ __device__ inline size_t lds_fixed_bytes(int n_pad) {
-  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + 64;
+  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + kWaves * kRowScratchBytes + 64;
 }
 // number of ring slots for this problem size (0 = does not fit)
 inline int plan_slots(int ks, int n_pad) {
@@ -191,32 +194,53 @@ __device__ __forceinline__ u32 lds_addr(const void* p) {
   return (u32)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// Issue the global->LDS copy of one B tile (KS pieces of 1 KiB) from the calling wave.
+// Producer side of the ring.  The KS pieces of a tile are dealt to NP producer waves, M pieces
+// each (KS = 12: waves 0..5 issue 2 pieces per tile), so no wave is held up for a whole tile's
+// worth of LDS-DMA issue.  Every producer wave has the same number of pieces in flight per tile,
+// which makes "my pieces of tile t have landed" a counted wait: vmcnt(M * tiles issued after t).
 template <int KS>
-__device__ inline void stage_tile(const uint8_t* __restrict__ tile_src, u32 slot_lds, int lane) {
+struct Producer {
+  static constexpr int M = KS <= 8 ? 1 : (KS + 7) / 8;
+  static constexpr int NP = KS / M;
+  static_assert(NP * M == KS && NP <= kWaves, "pieces must divide evenly over the producer waves");
+};
+
+template <int KS>
+__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ tile_src, u32 slot_lds, int wave, int lane) {
+  constexpr int M = Producer<KS>::M;
+  if (wave < Producer<KS>::NP) {
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk)
-    glds16(tile_src + kk * kFragBytes + lane * 16, slot_lds + kk * kFragBytes);
+    for (int m = 0; m < M; ++m) {
+      const int kk = wave * M + m;
+      glds16(tile_src + kk * kFragBytes + lane * 16, slot_lds + kk * kFragBytes);
+    }
+  }
 }
 
-// Similarity tiles of the wave's RT row tiles against one column tile + all top-2 updates.
-//
-// Exact int32 arithmetic on biased bytes: with a' = a-128, b' = b-128,
-//   s = sum a'b' + 128*ra + 128*rb - 16384*D = acc + ct[j] + rterm[i],
-//   acc = sum a'b' (MFMA, C = 0),  ct[j] = 128*rb[j] + 32640*D,  rterm[i] = 128*ra[i] - 49024*D,
-// and u = acc + ct satisfies 0 <= u <= 65025*D < 2^26.
-// Row search (fixed i): rterm is constant, so u orders the columns:
-//   rk = (acc << 6) + ((ct << 6) + jcode)                       one v_lshl_add_u32
-// Column search (fixed j): needs s itself:
-//   ck = (s << 6) + code(i) = rk + crow6[i] - jcode              one v_add3_u32
-//   with crow6[i] = (rterm[i] << 6) + code(i) read from LDS while the MFMAs run.
-// Each search then costs v_med3_u32 + v_max_u32: 6 VALU instructions per similarity in all.
-template <int KS, int RT, bool FUSED>
-__device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&rbest)[RT][16],
-                                             u32 (&rsec)[RT][16], const uint8_t* slot,
-                                             const int* crow6_wave, int lane, int h, int ct, u32 jcode,
-                                             u32& cb, u32& cs2) {
-  v16i acc[RT];
+// Wait until this wave's pieces of the oldest tile in flight have landed; `younger` tiles
+// (0..7) were issued after it.  s_waitcnt takes an immediate, hence the switch.
+template <int KS>
+__device__ __forceinline__ void wait_tile(int wave, int younger) {
+  constexpr int M = Producer<KS>::M;
+  if (wave < Producer<KS>::NP) {
+    switch (younger) {
+      case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0 * M) : "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * M) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * M) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * M) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * M) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * M) : "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * M) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * M) : "memory"); break;
+    }
+  }
+}
+
+// MFMA phase: similarity tiles of the wave's RT row tiles against one column tile.
+// acc = sum (a-128)(b-128) over k (C operand 0); the bias terms are added in the epilogue.
+template <int KS, int RT>
+__device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&acc)[RT], const uint8_t* slot,
+                                           int lane) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -224,7 +248,7 @@ __device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&r
   // K loop in groups of G fragments, the next group's LDS reads issued ahead of this group's
   // MFMAs; sched_barrier keeps the compiler from hoisting every read to the top (which costs
   // 4*KS registers and spills).
-  constexpr int G = KS < 4 ? KS : 4;
+  constexpr int G = (RT * KS >= 24) ? 2 : (KS < 4 ? KS : 4);  // smaller groups where registers are tight
   constexpr int NG = KS / G;
   static_assert(KS % G == 0, "KS must be a multiple of the fragment group");
   const uint8_t* src = slot + lane * 16;
@@ -249,39 +273,101 @@ __device__ __forceinline__ void process_tile(const v4i (&afrag)[RT][KS], u32 (&r
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// Epilogue phase: top-2 updates for one column tile.
+//
+// Exact int32 arithmetic on biased bytes: with a' = a-128, b' = b-128,
+//   s = sum a'b' + 128*ra + 128*rb - 16384*D = acc + rterm[i] + ct[j]          (one v_add3_u32)
+//   ct[j] = 128*rb[j] + 32640*D (per lane),  rterm[i] = 128*ra[i] - 49024*D (per register, LDS).
+//
+// Irrelevant similarities.  The launch passes s_low such that a similarity s <= s_low can never
+// influence the match list (see relevance_thresholds() for the proof sketch): it is too small to
+// be an accepted best, and as a runner-up it can never fail the ratio test of an acceptable best.
+// The searches may therefore ignore any such element.  Per 32x32 tile: one max over the lane's
+// 16 similarities (v_max3), and only if some lane of the wave holds a relevant one, only for the
+// registers (row pairs) that do, the actual updates:
+//   row search    key = s << 6 | (63 - column tile)          v_lshl_or, v_med3, v_max
+//   column search key = s << 6 | (63 - local row code)       v_lshl_or, v_med3, v_max
+// (s < 2^26: 255^2 * 1024 < 2^26.)  s_low = -1 disables the shortcut (every s >= 0 is relevant),
+// which is what the one-way API uses because it reports best / second for every row.
+//
+// The lane's column result goes to LDS with two atomics (col_merge), valid in any order:
+//   best64  = max over keys (s << 32 | ~row): highest s, lowest row on ties
+//   second  = max over { every lane's second } U { every best that is not THE best }: a best that
+//             loses its max contributes itself, one that wins contributes the value it displaced.
+template <int RT, bool FUSED>
+__device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbest)[RT][16], u32 (&rsec)[RT][16],
+                                               const int* rterm_wave, const int* cterm,
+                                               unsigned long long* colbest, u32* colsecond, int jt,
+                                               int c, int h, u32 row_base, int s_low) {
 #ifdef VC_EXP_NO_EPILOGUE
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) asm volatile("" :: "v"(acc[rt]));
   return;
 #endif
-  const u32 ctj = ((u32)ct << 6) + jcode;
-  const u32 negj = 0u - jcode;
+  const int ct = cterm[jt * kTile + c];
+  const u32 jcode = 63u - (u32)jt;
+  u32 cb = 0, cs2 = 0;
+  bool any_hit = false;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    v4i cr[4];
-    if (FUSED) {
+    // pass 1: largest similarity of this lane in the tile (similarities are not kept: registers)
+    int m = -1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) cr[q] = *(const v4i*)(crow6_wave + rt * kTile + 8 * q + 4 * h);
+    for (int q = 0; q < 4; ++q) {
+      const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
+      const int v0 = acc[rt][4 * q + 0] + cr[0] + ct, v1 = acc[rt][4 * q + 1] + cr[1] + ct;
+      const int v2 = acc[rt][4 * q + 2] + cr[2] + ct, v3 = acc[rt][4 * q + 3] + cr[3] + ct;
+      m = max(max(m, max(v0, v1)), max(v2, v3));
     }
+    if (__any(m > s_low)) {  // wave-uniform
+      any_hit = true;
+      // pass 2: recompute per register, update only where some lane is relevant
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const u32 rk = ((u32)acc[rt][r] << 6) + ctj;
-      rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
-      rbest[rt][r] = umax(rbest[rt][r], rk);
-      if (FUSED) {
-        const u32 ck = rk + (u32)cr[r >> 2][r & 3] + negj;
-        cs2 = umed3(cb, cs2, ck);
-        cb = umax(cb, ck);
+      for (int q = 0; q < 4; ++q) {
+        const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          const int v = acc[rt][r] + cr[i] + ct;
+          if (__any(v > s_low)) {  // wave-uniform: this register holds a relevant similarity
+            const u32 rk = ((u32)v << 6) | jcode;
+            rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
+            rbest[rt][r] = umax(rbest[rt][r], rk);
+            if (FUSED) {
+              const u32 ck = ((u32)v << 6) | (u32)(63 - (rt * kTile + (r & 3) + 8 * (r >> 2)));
+              cs2 = umed3(cb, cs2, ck);
+              cb = umax(cb, ck);
+            }
+          }
+        }
       }
     }
   }
+#ifndef VC_EXP_NO_COLATOMIC
+  if (FUSED && any_hit) {
+    if (cb != 0) {
+      const int j = jt * kTile + c;
+      const u32 sb = cb >> 6;
+      const u32 grow = row_base + (63u - (cb & 63u)) + 4u * h;
+      const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
+      const unsigned long long old = atomicMax(&colbest[j], key);
+      u32 cand = key > old ? (u32)(old >> 32) : sb;
+      cand = umax(cand, cs2 >> 6);
+      atomicMax(&colsecond[j], cand);
+    }
+  }
+#else
+  asm volatile("" :: "v"(cb), "v"(cs2));
+#endif
 }
 
 template <int KS, int RT, bool FUSED>
 __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
     const int32_t* __restrict__ pairs, float max_ratio, float max_distance, int cross_check,
-    int n_max, int ns, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts,
+    int n_max, int ns, int s_low, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts,
     // !FUSED: one-way outputs (rows of A against B)
     int32_t* __restrict__ o_idx, int32_t* __restrict__ o_best, int32_t* __restrict__ o_second) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -294,13 +380,14 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   int* rbest_s = m21 + n_pad;
   int* rsecond_s = rbest_s + n_pad;
   int* ridx_s = rsecond_s + n_pad;
-  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: column-search row constants
-  int* wave_count = crow6 + kWaves * 64;
+  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D
+  int* wave_count = crow6 + kWaves * 64 + kWaves * kRowScratchBytes / 4;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
+  uint2* rscratch = (uint2*)(crow6 + kWaves * 64) + wave * kRowScratchEntries;  // this wave's slice
 
   const int p = blockIdx.x;
   const int img_a = pairs[2 * p], img_b = pairs[2 * p + 1];
@@ -337,12 +424,19 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   // producer / consumer cursors over the tile sequence
   int prod_seq = 0, prod_jt = 0, prod_slot = 0;
   for (; prod_seq < pf && prod_seq < total; ++prod_seq) {
-    if (wave == (prod_seq & (kWaves - 1)))
-      stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring_lds + (u32)prod_slot * (KS * kFragBytes), lane);
+    stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
     if (++prod_jt == n_ct) prod_jt = 0;
     if (++prod_slot == ns) prod_slot = 0;
   }
   int cons_seq = 0, cons_slot = 0;
+  // The two waves of a SIMD (w and w+4) run half a tile apart: while waves 0-3 issue the MFMAs of
+  // tile t, waves 4-7 run the VALU epilogue of tile t-1, and vice versa, so the matrix pipe and the
+  // vector pipe of a SIMD work at the same time instead of being fought over in lockstep.
+#ifndef VC_NO_STAGGER
+  const bool late = wave >= kWaves / 2;
+#else
+  constexpr bool late = false;
+#endif
 
   for (int pass = 0; pass < n_pass; ++pass) {
     const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
@@ -360,54 +454,52 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows)
     int my_rterm = rbias;
     if (lane < RT * kTile) my_rterm = 128 * a_rowsum[tile0 * kTile + lane] + rbias;
-    if (FUSED && lane < RT * kTile) {
-      const int o = lane & 31;
-      const int code = 63 - ((lane & 32) + (o - 4 * ((o >> 2) & 1)));  // row code without the half-wave offset
-      crow6_wave[lane] = (int)(((u32)my_rterm << 6) + (u32)code);
+    if (lane < RT * kTile) crow6_wave[lane] = my_rterm;
+    const u32 row_base = (u32)(tile0 * kTile);
+    v16i acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = 0;
+
+    // one iteration = one column tile: wait for it, barrier, refill the slot freed by the
+    // previous iteration, then the two phases in the order of this wave's half
+#define VC_TILE_HEAD()                                                                              \
+    wait_tile<KS>(wave, prod_seq - cons_seq - 1);                                                   \
+    wg_barrier();                                                                                   \
+    if (prod_seq < total) {                                                                         \
+      stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes,                                   \
+                     ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);                    \
+      ++prod_seq;                                                                                   \
+      if (++prod_jt == n_ct) prod_jt = 0;                                                           \
+      if (++prod_slot == ns) prod_slot = 0;                                                         \
+    }                                                                                               \
+    const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;                               \
+    if (++cons_slot == ns) cons_slot = 0;                                                           \
+    ++cons_seq;
+
+    // Staggered halves (late = waves 4-7): one loop, the epilogue shared, only the MFMA phase
+    // placed before or after it.  The late half runs the epilogue of tile jt-1; for jt = 0 that
+    // call is neutralised by an unreachable threshold (its accumulators are not defined yet).
+    for (int jt = 0; jt < n_ct; ++jt) {
+      VC_TILE_HEAD()
+      if (!late) mfma_phase<KS, RT>(afrag, acc, slot, lane);
+      const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
+      const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
+      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, ejt, c, h, row_base, eth);
+      if (late) mfma_phase<KS, RT>(afrag, acc, slot, lane);
     }
+    if (late)
+      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low);
+#undef VC_TILE_HEAD
 
-    for (int jt = 0; jt < n_ct; ++jt, ++cons_seq) {
-      // tile cons_seq was issued by wave cons_seq % 8, which has nothing younger in flight
-      if (wave == (cons_seq & (kWaves - 1))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      wg_barrier();
-      // the slot consumed in the previous iteration is free: refill it PF tiles ahead
-      if (prod_seq < total) {
-        if (wave == (prod_seq & (kWaves - 1)))
-          stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring_lds + (u32)prod_slot * (KS * kFragBytes), lane);
-        ++prod_seq;
-        if (++prod_jt == n_ct) prod_jt = 0;
-        if (++prod_slot == ns) prod_slot = 0;
-      }
-
-      const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
-      if (++cons_slot == ns) cons_slot = 0;
-      const int ct = cterm[jt * kTile + c];
-      const u32 jcode = 63u - (u32)jt;
-      u32 cb = 0, cs2 = 0;
-      process_tile<KS, RT, FUSED>(afrag, rbest, rsec, slot, crow6_wave, lane, h, ct, jcode, cb, cs2);
-
-#ifndef VC_EXP_NO_COLATOMIC
-      if (FUSED) {
-        // col_merge: this lane's best / second over its rows of column j -> LDS, any order.
-        //   best64  = max over keys (s << 32 | ~row): highest s, lowest row on ties
-        //   second  = max over { every lane's second } U { every best that is not THE best }:
-        //             a best that loses its max contributes itself, one that wins contributes
-        //             the value it displaced.
-        const int j = jt * kTile + c;
-        const u32 sb = cb >> 6;
-        const u32 grow = (u32)(tile0 * kTile) + (63u - (cb & 63u)) + 4u * h;
-        const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
-        const unsigned long long old = atomicMax(&colbest[j], key);
-        u32 cand = key > old ? (u32)(old >> 32) : sb;
-        cand = umax(cand, cs2 >> 6);
-        atomicMax(&colsecond[j], cand);
-      }
-#else
-      asm volatile("" :: "v"(cb), "v"(cs2));
-#endif
-    }  // column tiles
-
-    // ---- row results of this pass: reduce over the 32 lanes that share a row ------------
+    // ---- row results of this pass ------------------------------------------------------
+    // Each row's candidates sit in 32 lanes (one per column residue c).  Transpose through a
+    // wave-private LDS slice, 16 rows per round: lane (c, h) writes its {best, second} keys of
+    // 8 registers, then lane L re-reads row L>>2, columns 8*(L&3) .. +7 in ascending order
+    // (strict '>' keeps the lowest column on ties) and the four partial results of a row are
+    // folded with two quad-permute steps.  No workgroup barrier: the slice belongs to the wave
+    // and its LDS operations execute in order.
 #ifdef VC_EXP_NO_ROWREDUCE
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -417,26 +509,45 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
 #endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const u32 m = half_max(rbest[rt][r]);
-          const unsigned long long eq = __ballot(rbest[rt][r] == m);
-          const int win = h ? __builtin_ctz((u32)(eq >> 32)) : __builtin_ctz((u32)eq);  // lowest column
-          const u32 x = (c == win) ? rsec[rt][r] : rbest[rt][r];
-          const u32 s2 = half_max(x);
-          // this row's term lives in lane (rt*32 + local row) of the wave
-          const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int rterm = __shfl(my_rterm, rt * kTile + lrow);
-          if (c == 0) {
-            const int row = (tile0 + rt) * kTile + lrow;
-            if (row < n1) {
-              const int sb = (int)(m >> 6) + rterm;
-              const int idx = sb > 0 ? (63 - (int)(m & 63)) * kTile + win : -1;
-              const int s2v = sb > 0 ? (int)(s2 >> 6) + rterm : 0;
-              if (FUSED) { rbest_s[row] = sb; rsecond_s[row] = s2v; ridx_s[row] = idx; }
-              else { o_idx[row] = idx; o_best[row] = sb; o_second[row] = s2v; }
-            }
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * half + j;
+          rscratch[(j + 8 * h) * 33 + c] = make_uint2(rbest[rt][r], rsec[rt][r]);
+        }
+        const int rl = lane >> 2, qd = lane & 3;       // row of the round, column quarter
+        u32 rb = 0, rs = 0, rc = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint2 en = rscratch[rl * 33 + qd * 8 + e];
+          const bool gt = en.x > rb;
+          rs = gt ? umax(rb, en.y) : umax(rs, en.x);
+          rc = gt ? (u32)(qd * 8 + e) : rc;
+          rb = umax(rb, en.x);
+        }
+        // fold quarters: the lower quarter absorbs the higher one (strict '>': lower column wins)
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+          u32 pb, ps, pc;
+          if (step == 0) { pb = dpp_mov<0xB1>(rb); ps = dpp_mov<0xB1>(rs); pc = dpp_mov<0xB1>(rc); }   // quad_perm [1,0,3,2]
+          else           { pb = dpp_mov<0x4E>(rb); ps = dpp_mov<0x4E>(rs); pc = dpp_mov<0x4E>(rc); }   // quad_perm [2,3,0,1]
+          const bool gt = pb > rb;
+          rs = gt ? umax(rb, ps) : umax(rs, pb);
+          rc = gt ? pc : rc;
+          rb = umax(rb, pb);
+        }
+        // row of this lane's result inside the wave's RT*32 rows (see the MFMA C layout)
+        const int jj = rl & 7, hh = rl >> 3;
+        const int lrow = (jj & 3) + 16 * half + 8 * (jj >> 2) + 4 * hh;
+        if (qd == 0) {
+          const int row = (tile0 + rt) * kTile + lrow;
+          if (row < n1) {
+            const int sb = (int)(rb >> 6);
+            const int idx = sb > 0 ? (63 - (int)(rb & 63)) * kTile + (int)rc : -1;
+            const int s2v = sb > 0 ? (int)(rs >> 6) : 0;
+            if (FUSED) { rbest_s[row] = sb; rsecond_s[row] = s2v; ridx_s[row] = idx; }
+            else { o_idx[row] = idx; o_best[row] = sb; o_second[row] = s2v; }
           }
         }
       }
@@ -540,6 +651,52 @@ __global__ void theta_table_kernel(float* out, int n) {
 // ---------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// relevance threshold (host side launch parameter)
+// ---------------------------------------------------------------------------------------
+// theta on the host, same definition as theta_dev (tests/test_matcher_gpu.py compares the
+// device table with the oracle's for every possible input).
+inline float theta_host(int s) {
+  float x = (float)s * (1.0f / (512.0f * 512.0f));
+  x = x > 1.0f ? 1.0f : x;
+  return (float)acos((double)x);
+}
+
+// Largest similarity that can be ignored by the searches without changing the match list.
+//   S_T   = smallest s with theta(s) <= max_distance: a best below it is always rejected.
+//   S_low = largest s (< S_T) with max_ratio * theta(s) > theta(S_T).
+// Take a row (or column) with top-2 (b, s2) and drop any elements <= S_low from its scan:
+//   b <  S_T : rejected before and after (the best can only shrink).
+//   b >= S_T : b > S_low, so the best and its index are untouched.  If s2 > S_low it is untouched
+//              too.  If s2 <= S_low, then max_ratio*theta(s2) >= max_ratio*theta(S_low) >
+//              theta(S_T) >= theta(b): the ratio test passes, and it passes just the same with
+//              whatever smaller runner-up is found instead.
+// theta is non-increasing in s and multiplication by a non-negative float is monotone, so both
+// thresholds are found by bisection.  A margin of 4 absorbs a last-bit difference between the
+// host's and the device's acos (one ulp of theta moves a threshold by < 0.01).
+// Returns -1 ("nothing can be ignored") for parameters outside the monotone regime.
+inline int relevance_threshold(float max_ratio, float max_distance) {
+  if (!(max_ratio >= 0.0f) || !(max_distance == max_distance)) return -1;
+  constexpr int kSat = 512 * 512;
+  if (theta_host(kSat) > max_distance) return kSat;  // nothing is ever accepted (max_distance < 0)
+  int lo = 0, hi = kSat;  // smallest s with theta(s) <= max_distance
+  while (lo < hi) {
+    const int mid = (lo + hi) / 2;
+    if (theta_host(mid) <= max_distance) hi = mid; else lo = mid + 1;
+  }
+  const int s_t = lo;
+  const float t_t = theta_host(s_t);
+  if (!(max_ratio * theta_host(0) > t_t)) return -1;
+  lo = 0; hi = s_t > 0 ? s_t - 1 : 0;  // largest s with max_ratio*theta(s) > t_t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) / 2;
+    if (max_ratio * theta_host(mid) > t_t) lo = mid; else hi = mid - 1;
+  }
+  int s_low = lo < s_t - 1 ? lo : s_t - 1;
+  s_low -= 4;
+  return s_low < -1 ? -1 : s_low;
+}
+
 // K-step counts with a compiled kernel; a descriptor is zero-padded up to the next one.
 constexpr int kKsList[] = {2, 4, 8, 12, 16, 24, 32};
 
@@ -555,6 +712,8 @@ int launch_pair(const void* prepared, const int32_t* counts, int n_tiles, int d,
                 int n_pairs, float max_ratio, float max_distance, int cross_check, int n_max,
                 uint32_t* out_matches, int32_t* out_counts, int32_t* o_idx, int32_t* o_best,
                 int32_t* o_second, hipStream_t stream) {
+  // the one-way API reports every row's best / second, so nothing may be skipped there
+  const int s_low = FUSED ? relevance_threshold(max_ratio, max_distance) : -1;
   const int n_pad = n_tiles * kTile;
   const int ns = plan_slots(KS, n_pad);
   if (ns == 0) return VC_ERR_UNSUPPORTED;
@@ -568,7 +727,7 @@ int launch_pair(const void* prepared, const int32_t* counts, int n_tiles, int d,
   }
   hipLaunchKernelGGL((pair_kernel<KS, RT, FUSED>), dim3(n_pairs), dim3(kThreads), smem, stream,
                      (const uint8_t*)prepared, counts, n_tiles, d, pairs, max_ratio, max_distance,
-                     cross_check, n_max, ns, out_matches, out_counts, o_idx, o_best, o_second);
+                     cross_check, n_max, ns, s_low, out_matches, out_counts, o_idx, o_best, o_second);
   return vc::check_launch();
 }
 
