@@ -98,6 +98,59 @@ int vc_mutual_ratio(const int32_t* idx12, const int32_t* best12, const int32_t* 
 /* Test hook: out[s] = theta(s) = angle assigned to integer similarity s, for s in [0, n). */
 int vc_theta_table(float* out, int n, vc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Keypoint selection + descriptors over the ViT token grid — replaces
+ * ViTExtractor._dense_to_sparse and helpers (reference vit_colmap/features/vit_extractor.py:168-653).
+ * Specification: oracle/select_oracle.py.  All functions are batched over n_images.
+ * ------------------------------------------------------------------------------------------ */
+#define VC_DTYPE_F32 0
+#define VC_DTYPE_BF16 1
+
+#define VC_METHOD_HARRIS 0   /* vit_extractor.py:281-348 */
+#define VC_METHOD_DOG 1      /* vit_extractor.py:350-394 */
+#define VC_METHOD_COMBINED 2 /* vit_extractor.py:271-277 */
+
+/*
+ * tokens [n_images][H*W][C] (float32 or bfloat16, token = y*W + x) -> st [n_images][4][H*W]:
+ * channel means of gx^2, gy^2, gx*gy (forward differences, zero at the last column / row) and
+ * the channel mean of the features (vit_extractor.py:298-309, 365).
+ */
+int vc_structure_tensor(const void* tokens, int token_dtype, int n_images, int H, int W, int C,
+                        float* st, vc_stream_t stream);
+
+/* st -> score [n_images][H*W] in [0,1] (method: VC_METHOD_*).  H*W <= 16384. */
+int vc_score_map(const float* st, int n_images, int H, int W, int method, float* score,
+                 vc_stream_t stream);
+
+/*
+ * score -> kept keypoints in score order: spatial binning with per-bin top-k (bin_size cells),
+ * global top-`target`, greedy NMS at `nms_radius` cells (vit_extractor.py:404-543).
+ * Total order everywhere: score descending, then position ascending.
+ * out_yx [n_images][kmax][2] (y, x), out_score [n_images][kmax], out_count [n_images].
+ * dbg_cand_* (all NULL or all non-NULL, same shapes): the candidate list before NMS.
+ * Limits: target <= 4096, H*W*8 + 80 KiB <= 159 KiB, nms_radius <= 8; kmax >= min(target, candidates).
+ */
+int vc_select_keypoints(const float* score, int n_images, int H, int W, int target, int bin_size,
+                        float nms_radius, int kmax, int32_t* out_yx, float* out_score,
+                        int32_t* out_count, int32_t* dbg_cand_yx, float* dbg_cand_score,
+                        int32_t* dbg_cand_count, vc_stream_t stream);
+
+/*
+ * Descriptors at the kept grid points: bilinear gather with the reference's grid_sample arithmetic
+ * (vit_extractor.py:545-586), optional projection desc @ proj ([C][dd] float32, NULL = none;
+ * vit_extractor.py:651), L2 normalisation (:243), uint8 quantisation clip(d*512, 0, 255) truncated
+ * (:250), and pixel coordinates (x + 0.5) * (resized_w / W) * (orig_w / resized_w) (:229-236).
+ * out_kp [n_images][kmax][2] float32 (x, y); out_desc_f32 (may be NULL) and out_desc_u8
+ * [n_images][kmax][dd or C]; rows >= count[i] are zero-filled (vc_prepare_descriptors reads them).
+ */
+int vc_describe(const void* tokens, int token_dtype, int n_images, int H, int W, int C,
+                const int32_t* yx, const int32_t* count, int kmax, const float* proj, int dd,
+                int resized_w, int resized_h, int orig_w, int orig_h, float* out_kp,
+                float* out_desc_f32, uint8_t* out_desc_u8, vc_stream_t stream);
+
+/* The quantiser alone: out[i] = (uint8) clip(in[i] * 512, 0, 255)   (vit_extractor.py:250). */
+int vc_quantize_u8(const float* in, uint8_t* out, size_t n, vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,13 @@ SIGNATURES = {
     "vc_mutual_ratio": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "vc_theta_table": (c_int, [c_void_p, c_int, c_void_p]),
+    "vc_structure_tensor": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vc_score_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vc_select_keypoints": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vc_describe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vc_quantize_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,252 @@
+"""DINOv2 ViT patch-token forward for PyTorch-ROCm (bf16 on MFMA via hipBLASLt / SDPA).
+
+The reference obtains this network with `torch.hub.load("facebookresearch/dinov2", name)`
+(vit_colmap/features/vit_extractor.py:86-104) and reads `x_norm_patchtokens` from
+`forward_features` (:135-146).  There is no network here, so the architecture is defined locally
+with the hub checkpoint's parameter names (a DINOv2 state dict loads with `load_state_dict`),
+and `forward_patch_tokens` returns the same quantity: post-final-LayerNorm patch tokens
+(B, Hp*Wp, C), token index = y*Wp + x.
+
+MI355X-first choices
+  * the image is consumed already patchified, (B, Hp*Wp, 3*14*14): the HIP preprocessing kernel
+    (csrc/preprocess.hip) writes that layout directly, so the patch embedding is ONE GEMM instead
+    of a strided 14x14 convolution;
+  * qkv / proj / MLP are plain bf16 GEMMs over B*N rows (hipBLASLt picks the MFMA kernels), the
+    attention is `scaled_dot_product_attention` on (B, heads, N, 64);
+  * LayerScale is folded into the projection weights at load time (one multiply per element less);
+  * the whole forward is shape-static per batch size, so the extractor captures it in a hipGraph.
+
+Architecture facts [recalled from the DINOv2 repository; pinned by tests/test_vit.py against the
+`transformers` Dinov2 implementation that ships in this image]: pre-norm blocks
+x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)); LayerNorm eps 1e-6; exact (erf) GELU;
+bicubic position-embedding interpolation with the 0.1 scale-factor offset of the hub models.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+PATCH = 14
+
+
+@dataclass(frozen=True)
+class Arch:
+    dim: int
+    depth: int
+    heads: int
+    ffn: str = "mlp"            # "mlp" | "swiglu"
+    registers: int = 0
+    img_size: int = 518
+
+
+DINOV2_ARCHS = {
+    "dinov2_vits14": Arch(384, 12, 6),
+    "dinov2_vitb14": Arch(768, 12, 12),
+    "dinov2_vitl14": Arch(1024, 24, 16),
+    "dinov2_vitg14": Arch(1536, 40, 24, ffn="swiglu"),
+    "dinov2_vits14_reg": Arch(384, 12, 6, registers=4),
+    "dinov2_vitb14_reg": Arch(768, 12, 12, registers=4),
+    "dinov2_vitl14_reg": Arch(1024, 24, 16, registers=4),
+    "dinov2_vitg14_reg": Arch(1536, 40, 24, ffn="swiglu", registers=4),
+}
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=PATCH, stride=PATCH)  # checkpoint-compatible parameter shapes
+
+    def forward_patches(self, patches):
+        """patches (B, N, 3*14*14) in (c, dy, dx) order -> (B, N, dim): the convolution as a GEMM."""
+        w = self.proj.weight.reshape(self.proj.weight.shape[0], -1)
+        return F.linear(patches, w, self.proj.bias)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class SwiGLUFFNFused(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        hidden = (int(hidden * 2 / 3) + 7) // 8 * 8
+        self.w12 = nn.Linear(dim, 2 * hidden)
+        self.w3 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        x1, x2 = self.w12(x).chunk(2, dim=-1)
+        return self.w3(F.silu(x1) * x2)
+
+
+class LayerScale(nn.Module):
+    def __init__(self, dim, init=1.0):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class Block(nn.Module):
+    def __init__(self, arch: Arch):
+        super().__init__()
+        d = arch.dim
+        self.norm1 = nn.LayerNorm(d, eps=1e-6)
+        self.attn = Attention(d, arch.heads)
+        self.ls1 = LayerScale(d)
+        self.norm2 = nn.LayerNorm(d, eps=1e-6)
+        self.mlp = Mlp(d, 4 * d) if arch.ffn == "mlp" else SwiGLUFFNFused(d, 4 * d)
+        self.ls2 = LayerScale(d)
+        self.folded = False
+
+    def forward(self, x):
+        if self.folded:  # LayerScale already multiplied into attn.proj / the last MLP layer
+            x = x + self.attn(self.norm1(x))
+            return x + self.mlp(self.norm2(x))
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class DinoV2(nn.Module):
+    def __init__(self, arch: Arch, interpolate_offset: float = 0.1):
+        super().__init__()
+        self.arch = arch
+        self.interpolate_offset = interpolate_offset
+        d = arch.dim
+        m = arch.img_size // PATCH
+        self.patch_embed = PatchEmbed(d)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, d))
+        self.pos_embed = nn.Parameter(torch.zeros(1, 1 + m * m, d))
+        self.register_tokens = nn.Parameter(torch.zeros(1, arch.registers, d)) if arch.registers else None
+        self.mask_token = nn.Parameter(torch.zeros(1, d))  # present in checkpoints, unused at inference
+        self.blocks = nn.ModuleList([Block(arch) for _ in range(arch.depth)])
+        self.norm = nn.LayerNorm(d, eps=1e-6)
+        self._pos_cache = {}
+
+    # -- weights --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def init_random(self, seed: int = 0):
+        """Seeded random weights of trained-checkpoint scale (there is no network for the real ones)."""
+        g = torch.Generator().manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("gamma"):
+                p.fill_(1.0)
+            elif p.dim() == 1:
+                if "norm" in name and name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+            else:
+                fan_in = p[0].numel() if p.dim() > 1 else p.numel()
+                std = 0.02 if name in ("cls_token", "pos_embed", "register_tokens", "mask_token") else 1.0 / math.sqrt(fan_in)
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+        return self
+
+    @torch.no_grad()
+    def fold_layerscale(self):
+        """x*gamma after a Linear == Linear with rows of W and b scaled by gamma (exact in real
+        arithmetic; done in float32 before any cast to bf16)."""
+        for b in self.blocks:
+            if b.folded:
+                continue
+            last = b.mlp.fc2 if isinstance(b.mlp, Mlp) else b.mlp.w3
+            for lin, ls in ((b.attn.proj, b.ls1), (last, b.ls2)):
+                lin.weight.mul_(ls.gamma[:, None])
+                lin.bias.mul_(ls.gamma)
+            b.folded = True
+        return self
+
+    # -- position embedding -----------------------------------------------------------------------
+    def interpolated_pos_embed(self, hp: int, wp: int):
+        """(1, 1 + hp*wp, C): bicubic resize of the learned M x M grid (cached per grid size).
+        With interpolate_offset the scale factor (hp + 0.1) / M is handed to `interpolate`, as the
+        hub models do; 0 switches to size-based interpolation (the `transformers` behaviour)."""
+        key = (hp, wp, self.pos_embed.dtype, self.pos_embed.device)
+        if key in self._pos_cache:
+            return self._pos_cache[key]
+        pe = self.pos_embed.float()
+        n = pe.shape[1] - 1
+        m = int(math.sqrt(n))
+        if hp == m and wp == m:
+            out = self.pos_embed
+        else:
+            grid = pe[:, 1:].reshape(1, m, m, -1).permute(0, 3, 1, 2)
+            if self.interpolate_offset:
+                sf = (float(hp + self.interpolate_offset) / m, float(wp + self.interpolate_offset) / m)
+                grid = F.interpolate(grid, scale_factor=sf, mode="bicubic", antialias=False)
+            else:
+                grid = F.interpolate(grid, size=(hp, wp), mode="bicubic", align_corners=False)
+            assert grid.shape[-2:] == (hp, wp)
+            out = torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, hp * wp, -1)], dim=1).to(self.pos_embed.dtype)
+        self._pos_cache[key] = out
+        return out
+
+    # -- forward ------------------------------------------------------------------------------------
+    def forward_patch_tokens(self, patches: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
+        """patches (B, hp*wp, 588) -> x_norm_patchtokens (B, hp*wp, C)."""
+        B = patches.shape[0]
+        x = self.patch_embed.forward_patches(patches)
+        x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.interpolated_pos_embed(hp, wp)
+        if self.register_tokens is not None:
+            x = torch.cat([x[:, :1], self.register_tokens.expand(B, -1, -1), x[:, 1:]], dim=1)
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.norm(x)
+        return x[:, 1 + self.arch.registers:]
+
+    def forward_features(self, image: torch.Tensor):
+        """(B, 3, H, W) normalised image -> dict with 'x_norm_patchtokens', the key the reference
+        reads (vit_extractor.py:140-142).  H and W must be multiples of 14."""
+        B, _, H, W = image.shape
+        hp, wp = H // PATCH, W // PATCH
+        patches = image.reshape(B, 3, hp, PATCH, wp, PATCH).permute(0, 2, 4, 1, 3, 5).reshape(B, hp * wp, 3 * PATCH * PATCH)
+        return {"x_norm_patchtokens": self.forward_patch_tokens(patches, hp, wp)}
+
+
+def build_dinov2(model_name: str = "dinov2_vitb14", interpolate_offset: float = 0.1) -> DinoV2:
+    if model_name not in DINOV2_ARCHS:
+        raise ValueError(f"Unsupported model: {model_name}. Currently only DINOv2 models are supported.")
+    return DinoV2(DINOV2_ARCHS[model_name], interpolate_offset)
+
+
+def load_dinov2_weights(model: DinoV2, path: str) -> DinoV2:
+    """Load a DINOv2 checkpoint (hub parameter names) from .safetensors or a weights-only .pth."""
+    if str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+
+        sd = load_file(str(path))
+    else:
+        sd = torch.load(str(path), map_location="cpu", weights_only=True)
+        for key in ("model_state_dict", "state_dict"):
+            if isinstance(sd, dict) and key in sd:
+                sd = sd[key]
+    try:
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+    except RuntimeError as e:  # shape mismatch: wrong architecture for this checkpoint
+        raise ValueError(f"checkpoint does not fit {model.arch}: {str(e)[:300]}") from None
+    missing = [k for k in missing if k != "mask_token"]
+    if missing or unexpected:
+        raise ValueError(f"checkpoint does not fit {model.arch}: missing {missing[:5]}, unexpected {unexpected[:5]}")
+    return model
