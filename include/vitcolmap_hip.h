@@ -151,6 +151,22 @@ int vc_describe(const void* tokens, int token_dtype, int n_images, int H, int W,
 /* The quantiser alone: out[i] = (uint8) clip(in[i] * 512, 0, 255)   (vit_extractor.py:250). */
 int vc_quantize_u8(const float* in, uint8_t* out, size_t n, vc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Image preprocessing — replaces reference vit_extractor.py:117-132 (BGR->RGB, resize to
+ * multiples of 14 with cv2.INTER_LINEAR, /255, ImageNet mean/std), batched.
+ * ------------------------------------------------------------------------------------------ */
+#define VC_LAYOUT_NCHW 0    /* out [n][3][out_h][out_w]                                        */
+#define VC_LAYOUT_PATCHES 1 /* out [n][(out_h/14)*(out_w/14)][3*14*14], element (c, dy, dx)    */
+
+/*
+ * images_bgr [n_images][h][w][3] uint8 -> model input (float32 or bfloat16, VC_DTYPE_*).
+ * The frame is resized only if (out_h, out_w) != (h, w).  resized_bgr_or_null (optional,
+ * [n_images][out_h][out_w][3] uint8) receives the resized 8-bit frame for inspection.
+ */
+int vc_preprocess_u8(const uint8_t* images_bgr, int n_images, int h, int w, int out_h, int out_w,
+                     int out_dtype, int layout, void* out, uint8_t* resized_bgr_or_null,
+                     vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

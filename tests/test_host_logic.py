@@ -1,0 +1,183 @@
+"""CPU tests of the host-side mirror of the reference interface: config, database writer,
+Dummy extractor, image I/O, pipeline dispatch and error conventions."""
+import sqlite3
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from vit_colmap_amd.database import ColmapDatabase, SqliteColmapDatabase, pair_id_of, pair_id_to_image_ids
+from vit_colmap_amd.features import BaseExtractor, DummyExtractor
+from vit_colmap_amd.features.base_extractor import default_camera_params, list_images
+from vit_colmap_amd.utils import Config, MatchingConfig, image_io
+
+
+def checkerboard(w=640, h=480, tile=40):
+    """reference tests/test_smoke_e2e.py:10-17"""
+    img = np.zeros((h, w, 3), np.uint8)
+    for y in range(0, h, tile):
+        for x in range(0, w, tile):
+            if ((x // tile) + (y // tile)) % 2 == 0:
+                img[y:y + tile, x:x + tile] = 255
+    return img
+
+
+def test_config_defaults_match_reference():
+    c = Config()
+    assert c.extractor.extractor_type == "vit" and c.camera.model == "SIMPLE_PINHOLE"
+    assert (c.matching.max_ratio, c.matching.max_distance, c.matching.cross_check) == (0.8, 0.7, True)
+    assert c.matching.use_gpu is True and c.matching.num_threads == -1
+    assert c.do_matching and c.do_reconstruction and c.reconstruction.min_num_matches == 15
+    o = c.matching.to_matching_options()
+    assert (o.sift.max_ratio, o.sift.max_distance, o.sift.cross_check) == (0.8, 0.7, True)
+    legacy = MatchingConfig(max_ratio=0.9)._to_sift_options_legacy()
+    assert legacy.max_ratio == 0.9
+    assert "Extractor: vit" in c.summary()
+    assert c.camera.get_default_params(640, 480) == [640, 320.0, 240.0]
+
+    class A:
+        camera_model = "PINHOLE"; extractor = "dummy"; vit_weights = None; skip_matching = True
+        skip_reconstruction = True; verbose = False
+    c2 = Config.from_args(A())
+    assert c2.camera.model == "PINHOLE" and c2.extractor.extractor_type == "dummy"
+    assert not c2.do_matching and not c2.do_reconstruction
+
+
+def test_camera_defaults_and_errors():
+    assert default_camera_params("PINHOLE", 640, 480) == [640, 640, 320.0, 240.0]
+    with pytest.raises(ValueError, match="Unsupported camera model"):
+        default_camera_params("FISHEYE", 1, 1)
+
+
+def test_database_schema_roundtrip_and_reference_sql(tmp_path):
+    path = tmp_path / "database.db"
+    db = ColmapDatabase(str(path))
+    cam = db.add_pinhole_camera(640, 480, 640.0, 640.0, 320.0, 240.0)
+    ids = [db.add_image(f"image_{i:03d}.png", cam) for i in range(3)]
+    assert ids == [1, 2, 3]                                        # test_smoke_e2e.py:68 relies on 1..3
+    kp = np.arange(12, dtype=np.float64).reshape(6, 2)
+    desc = (np.arange(6 * 128) % 256).reshape(6, 128)
+    db.add_keypoints(1, kp)
+    db.add_descriptors(1, desc)
+    db.add_matches(2, 1, np.array([[0, 5], [3, 4]]))               # reversed ids: stored relative to (1, 2)
+    db.add_matches(1, 3, np.zeros((0, 2)))
+    db.commit()
+    db.db.close()
+    with ColmapDatabase.open_database(str(path)) as h:
+        assert ColmapDatabase.get_db_count(h, "num_cameras") == 1
+        assert ColmapDatabase.get_db_count(h, "num_images") == 3
+        assert ColmapDatabase.get_db_count(h, "num_matched_image_pairs") == 2
+        assert h.exists_keypoints(1) and h.exists_descriptors(1) and not h.exists_keypoints(2)
+        assert h.read_keypoints(1).dtype == np.float32 and np.array_equal(h.read_keypoints(1), kp)
+        assert h.read_descriptors(1).dtype == np.uint8 and np.array_equal(h.read_descriptors(1), desc)
+        assert np.array_equal(h.read_matches(1, 2), [[5, 0], [4, 3]])
+        assert np.array_equal(h.read_matches(2, 1), [[0, 5], [3, 4]])
+        assert h.read_matches(1, 3).shape == (0, 2)
+        assert h.read_camera(1).model == "PINHOLE"
+    # the SQL the reference itself runs (metrics.py:158,197,202,207; test_vit_integration.py:129-138,209-213)
+    conn = sqlite3.connect(str(path))
+    cur = conn.cursor()
+    assert cur.execute("SELECT COUNT(*) FROM images").fetchone()[0] == 3
+    assert cur.execute("SELECT image_id, rows, cols FROM keypoints").fetchall() == [(1, 6, 2)]
+    assert cur.execute("SELECT image_id, rows, cols FROM descriptors").fetchall() == [(1, 6, 128)]
+    assert sorted(cur.execute("SELECT pair_id, rows FROM matches").fetchall()) == [
+        (pair_id_of(1, 2), 2), (pair_id_of(1, 3), 0)]
+    assert cur.execute("SELECT pair_id, rows, config FROM two_view_geometries").fetchall() == []
+    conn.close()
+    assert pair_id_of(2, 1) == 2147483647 + 2 and pair_id_to_image_ids(pair_id_of(7, 3)) == (3, 7)
+
+
+def test_unique_image_names_and_bad_camera(tmp_path):
+    db = SqliteColmapDatabase(str(tmp_path / "d.db"))
+    from vit_colmap_amd.database import Camera, Image
+
+    cid = db.write_camera(Camera("SIMPLE_PINHOLE", 10, 10, [10, 5, 5]))
+    db.write_image(Image("a.png", cid))
+    with pytest.raises(sqlite3.IntegrityError):
+        db.write_image(Image("a.png", cid))
+    with pytest.raises(ValueError):
+        db.write_camera(Camera("NOT_A_MODEL", 1, 1, []))
+    db.close()
+
+
+def test_image_io_roundtrip_and_listing(tmp_path):
+    img = checkerboard()
+    img[..., 0] = 10                                                # make B and R differ
+    assert image_io.imwrite(tmp_path / "b.png", img)
+    image_io.imwrite(tmp_path / "a.PNG", img)
+    (tmp_path / "notes.txt").write_text("x")
+    back = image_io.imread(tmp_path / "b.png")
+    assert back.dtype == np.uint8 and np.array_equal(back, img)     # BGR in, BGR out
+    assert image_io.imread(tmp_path / "notes.txt") is None
+    assert [f.name for f in list_images(tmp_path)] == ["a.PNG", "b.png"]
+
+
+def test_dummy_extractor_contract(tmp_path):
+    assert issubclass(DummyExtractor, BaseExtractor)
+    d = tmp_path / "images"
+    d.mkdir()
+    for i, shift in enumerate([(0, 0), (50, 30), (100, 60)]):
+        image_io.imwrite(d / f"image_{i:03d}.png", np.roll(checkerboard(), shift, (1, 0)))
+    db_path = tmp_path / "database.db"
+    DummyExtractor(step=32).extract(d, db_path, "PINHOLE")
+    g = np.load(Path(__file__).parent / "golden" / "dummy_640x480.npz")
+    with ColmapDatabase.open_database(str(db_path)) as db:
+        assert db.num_images() == 3 and db.num_cameras() == 1
+        for i in (1, 2, 3):
+            assert np.array_equal(db.read_keypoints(i), g["keypoints"])
+            assert np.array_equal(db.read_descriptors(i), g["descriptors"])
+        assert db.read_camera(1).params == list(g["camera_params"])
+    with pytest.raises(ValueError):
+        DummyExtractor().extract(d, tmp_path / "x.db", "FISHEYE")
+
+
+def test_dummy_extractor_generates_images_when_dir_is_empty(tmp_path):
+    d = tmp_path / "empty"
+    DummyExtractor().extract(d, tmp_path / "db.db", "SIMPLE_PINHOLE")       # dummy_extractor.py:46-55
+    assert len(list_images(d)) == 10
+    with ColmapDatabase.open_database(str(tmp_path / "db.db")) as db:
+        assert db.num_images() == 10
+
+
+def test_vit_extractor_error_conventions(tmp_path):
+    from vit_colmap_amd.features.vit_extractor import ViTExtractor
+
+    with pytest.raises(ValueError, match="Unsupported model"):
+        ViTExtractor(model_name="resnet50", device="cpu")
+    with pytest.raises(ValueError, match="Unknown detection method"):
+        ViTExtractor(model_name="dinov2_vits14", detection_method="fast", device="cpu")
+    ex = ViTExtractor(model_name="dinov2_vits14", num_keypoints=64, descriptor_dim=384, device="cpu")
+    empty = tmp_path / "none"
+    empty.mkdir()
+    with pytest.raises(ValueError, match="No images found"):
+        ex.extract(empty, tmp_path / "a.db", "PINHOLE")
+    (empty / "broken.png").write_bytes(b"not a png")
+    with pytest.raises(ValueError, match="Failed to read first image"):
+        ex.extract(empty, tmp_path / "b.db", "PINHOLE")
+    d = tmp_path / "imgs"
+    d.mkdir()
+    image_io.imwrite(d / "x.png", checkerboard())
+    with pytest.raises(ValueError, match="Unsupported camera model"):
+        ex.extract(d, tmp_path / "c.db", "FISHEYE")
+    from vit_colmap_amd._lib import HipLibraryError
+
+    with pytest.raises(HipLibraryError):                           # no GPU here: must fail loudly
+        ex._run_inference(checkerboard())
+
+
+def test_pipeline_dispatch(tmp_path):
+    from vit_colmap_amd.pipeline import Pipeline
+
+    c = Config()
+    c.extractor.extractor_type = "colmap_sift"
+    with pytest.raises(NotImplementedError):
+        Pipeline(c).run(tmp_path, tmp_path / "o", tmp_path / "d.db")
+    c.extractor.extractor_type = "dummy"
+    c.camera.model = "PINHOLE"
+    c.do_matching = False
+    c.do_reconstruction = False
+    d = tmp_path / "images"
+    d.mkdir()
+    image_io.imwrite(d / "a.png", checkerboard())
+    assert Pipeline(c).run(d, tmp_path / "out", tmp_path / "db" / "database.db") is None
+    assert (tmp_path / "out").exists() and (tmp_path / "db" / "database.db").exists()

@@ -1,0 +1,118 @@
+// Image preprocessing for the ViT: uint8 BGR frames -> resized, RGB, ImageNet-normalised model
+// input, written either as NCHW or directly in patch order (B, Hp*Wp, 3*14*14) so that the patch
+// embedding is a single GEMM.
+//
+// Replaces reference vit_colmap/features/vit_extractor.py:117-132:
+//   cv2.cvtColor(BGR2RGB); floor H, W to multiples of 14; cv2.resize(INTER_LINEAR) if they
+//   changed; ToTensor (/255); Normalize(mean, std).
+// The resize restates OpenCV's 8-bit bilinear path [recalled: cv2 is not installed here, so this
+// step is PARITY UNPINNED against cv2 itself]: half-pixel centres, coefficients rounded to 11-bit
+// fixed point, horizontal pass in int32, vertical pass
+//   ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+// Specification and bit-exact target: oracle/preprocess_oracle.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vitcolmap_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int kPatch = 14;
+
+struct Coef {  // one source index and its two 11-bit weights
+  int s0, s1;
+  int a0, a1;
+};
+
+__device__ inline Coef linear_coef(int d, int src, double scale) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= src - 1) { f = 0.f; s = src - 1; }
+  Coef c;
+  c.s0 = s;
+  c.s1 = min(s + 1, src - 1);
+  // saturate_cast<short>(x * 2048): round half to even
+  c.a0 = (int)rintf((1.f - f) * 2048.f);
+  c.a1 = (int)rintf(f * 2048.f);
+  return c;
+}
+
+__device__ inline uint16_t f32_to_bf16(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename OutT>
+__device__ inline void store(OutT* p, float v);
+template <>
+__device__ inline void store<float>(float* p, float v) { *p = v; }
+template <>
+__device__ inline void store<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ img, int h, int w, int oh,
+                                                         int ow, int layout, OutT* __restrict__ out,
+                                                         uint8_t* __restrict__ resized_dbg) {
+  const int n = blockIdx.y;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= oh * ow) return;
+  const int y = idx / ow, x = idx - y * ow;
+  const uint8_t* src = img + (size_t)n * h * w * 3;
+  int px[3];
+  if (oh == h && ow == w) {
+    for (int c = 0; c < 3; ++c) px[c] = src[((size_t)y * w + x) * 3 + c];
+  } else {
+    const Coef cx = linear_coef(x, w, (double)w / (double)ow);
+    const Coef cy = linear_coef(y, h, (double)h / (double)oh);
+    for (int c = 0; c < 3; ++c) {
+      const int r0 = src[((size_t)cy.s0 * w + cx.s0) * 3 + c] * cx.a0 + src[((size_t)cy.s0 * w + cx.s1) * 3 + c] * cx.a1;
+      const int r1 = src[((size_t)cy.s1 * w + cx.s0) * 3 + c] * cx.a0 + src[((size_t)cy.s1 * w + cx.s1) * 3 + c] * cx.a1;
+      px[c] = (((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    }
+  }
+  if (resized_dbg)
+    for (int c = 0; c < 3; ++c) resized_dbg[(((size_t)n * oh + y) * ow + x) * 3 + c] = (uint8_t)px[c];
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int hp = oh / kPatch, wp = ow / kPatch;
+  for (int c = 0; c < 3; ++c) {
+    const float t = (float)px[2 - c] / 255.0f;  // channel c of RGB is channel 2-c of BGR
+    const float v = (t - mean[c]) / stdv[c];
+    size_t o;
+    if (layout == VC_LAYOUT_NCHW) {
+      o = (((size_t)n * 3 + c) * oh + y) * ow + x;
+    } else {
+      const int py = y / kPatch, dy = y - py * kPatch, pxx = x / kPatch, dx = x - pxx * kPatch;
+      o = ((size_t)n * hp * wp + (size_t)py * wp + pxx) * (3 * kPatch * kPatch) + (c * kPatch + dy) * kPatch + dx;
+    }
+    store<OutT>(out + o, v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_preprocess_u8(const uint8_t* images_bgr, int n_images, int h, int w, int out_h, int out_w, int out_dtype,
+                     int layout, void* out, uint8_t* resized_bgr_or_null, vc_stream_t stream) {
+  if (!images_bgr || !out || n_images < 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0) return VC_ERR_INVALID_ARG;
+  if (out_dtype != VC_DTYPE_F32 && out_dtype != VC_DTYPE_BF16) return VC_ERR_INVALID_ARG;
+  if (layout != VC_LAYOUT_NCHW && layout != VC_LAYOUT_PATCHES) return VC_ERR_INVALID_ARG;
+  if (layout == VC_LAYOUT_PATCHES && (out_h % kPatch != 0 || out_w % kPatch != 0)) return VC_ERR_INVALID_ARG;
+  if (n_images == 0) return VC_OK;
+  const dim3 grid((out_h * out_w + 255) / 256, n_images);
+  if (out_dtype == VC_DTYPE_F32)
+    hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, images_bgr, h, w, out_h,
+                       out_w, layout, (float*)out, resized_bgr_or_null);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, images_bgr, h, w,
+                       out_h, out_w, layout, (uint16_t*)out, resized_bgr_or_null);
+  return vc::check_launch();
+}
+
+}  // extern "C"
