@@ -135,6 +135,20 @@ class ViTExtractor(BaseExtractor):
             print(f"Initialized random projection (insufficient samples): {C} -> {self.descriptor_dim}")
 
     @torch.inference_mode()
+    def extract_device(self, images_bgr: torch.Tensor):
+        """Device-resident batch API: uint8 (B, h, w, 3) already in HBM -> dict of GPU tensors
+        (keypoints (B, K, 2) float32, desc_u8 (B, K, D) uint8 zero-padded, count (B,) int32).
+        This is what bench.py and the multi-GPU path call; nothing is copied to the host."""
+        self._require_gpu()
+        B, h, w, _ = images_bgr.shape
+        h_new, w_new = (h // PATCH) * PATCH, (w // PATCH) * PATCH
+        tokens, hp, wp = self._tokens(images_bgr)
+        self._ensure_projection(tokens, hp, wp, (w, h), (w_new, h_new))
+        proj = self.descriptor_projection if tokens.shape[-1] > self.descriptor_dim else None
+        return hip_select.dense_to_sparse(tokens, hp, wp, (w, h), (w_new, h_new), self.num_keypoints,
+                                          self.detection_method, proj)
+
+    @torch.inference_mode()
     def _run_batch(self, images_bgr_np):
         """list of equal-size BGR uint8 arrays -> list of (keypoints (N, 2) float32, descriptors (N, D) uint8)."""
         self._require_gpu()
