@@ -168,7 +168,11 @@ inline int plan_slots(int ks, int n_pad) {
 
 __device__ inline void wg_barrier() {
   // LDS writes/atomics of this wave are complete before it arrives; LDS-DMA stays in flight
+#ifdef VC_EXP_NO_BARRIER
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // One 1 KiB LDS-DMA piece: 64 lanes x 16 B, global source per lane, LDS destination =
@@ -208,6 +212,9 @@ struct Producer {
 template <int KS>
 __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ tile_src, u32 slot_lds, int wave, int lane) {
   constexpr int M = Producer<KS>::M;
+#ifdef VC_EXP_NO_STAGE
+  return;
+#endif
   if (wave < Producer<KS>::NP) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -254,13 +261,20 @@ __device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&ac
   const uint8_t* src = slot + lane * 16;
   v4i bf[2][G];
 #pragma unroll
+#ifdef VC_EXP_NO_LDSREAD
+  for (int i = 0; i < G; ++i) { bf[0][i] = afrag[0][i]; bf[1][i] = afrag[0][(i + 1) % KS]; }
+  asm volatile("" :: "v"(src));
+#else
   for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
+#endif
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
+#ifndef VC_EXP_NO_LDSREAD
     if (g + 1 < NG) {
 #pragma unroll
       for (int i = 0; i < G; ++i) bf[(g + 1) & 1][i] = *(const v4i*)(src + ((g + 1) * G + i) * kFragBytes);
     }
+#endif
 #pragma unroll
     for (int i = 0; i < G; ++i)
 #pragma unroll
@@ -285,8 +299,7 @@ __device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&ac
 // influence the match list (see relevance_thresholds() for the proof sketch): it is too small to
 // be an accepted best, and as a runner-up it can never fail the ratio test of an acceptable best.
 // The searches may therefore ignore any such element.  Per 32x32 tile: one max over the lane's
-// 16 similarities (v_max3), and only if some lane of the wave holds a relevant one, only for the
-// registers (row pairs) that do, the actual updates:
+// 16 similarities, and only if some lane of the wave holds a relevant one, the actual updates:
 //   row search    key = s << 6 | (63 - column tile)          v_lshl_or, v_med3, v_max
 //   column search key = s << 6 | (63 - local row code)       v_lshl_or, v_med3, v_max
 // (s < 2^26: 255^2 * 1024 < 2^26.)  s_low = -1 disables the shortcut (every s >= 0 is relevant),
@@ -300,11 +313,17 @@ template <int RT, bool FUSED>
 __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbest)[RT][16], u32 (&rsec)[RT][16],
                                                const int* rterm_wave, const int* cterm,
                                                unsigned long long* colbest, u32* colsecond, int jt,
-                                               int c, int h, u32 row_base, int s_low) {
+                                               int c, int h, u32 row_base, int s_low, bool (&dense)[RT]) {
 #ifdef VC_EXP_NO_EPILOGUE
+  {
+    int keep = 0;
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) asm volatile("" :: "v"(acc[rt]));
-  return;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) keep ^= acc[rt][r];
+    asm volatile("" :: "v"(keep));
+    return;
+  }
 #endif
   const int ct = cterm[jt * kTile + c];
   const u32 jcode = 63u - (u32)jt;
@@ -312,37 +331,49 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
   bool any_hit = false;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    // pass 1: largest similarity of this lane in the tile (similarities are not kept: registers)
-    int m = -1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
-      const int v0 = acc[rt][4 * q + 0] + cr[0] + ct, v1 = acc[rt][4 * q + 1] + cr[1] + ct;
-      const int v2 = acc[rt][4 * q + 2] + cr[2] + ct, v3 = acc[rt][4 * q + 3] + cr[3] + ct;
-      m = max(max(m, max(v0, v1)), max(v2, v3));
-    }
-    if (__any(m > s_low)) {  // wave-uniform
-      any_hit = true;
-      // pass 2: recompute per register, update only where some lane is relevant
+    // Two regimes, chosen per row tile from what the previous column tile looked like (wave-uniform):
+    //   sparse: pass 1 computes the lane's largest similarity only (24 VALU); if some lane is
+    //           relevant, pass 2 recomputes the similarities and updates (and switches to dense);
+    //   dense : one pass that updates and tracks the maximum (SIFT-like descriptors sit at
+    //           cos ~0.64, right at the threshold: there almost every tile is relevant).
+    bool update = dense[rt];
+    if (!update) {
+      int m = -1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
+        const int v0 = acc[rt][4 * q + 0] + cr[0] + ct, v1 = acc[rt][4 * q + 1] + cr[1] + ct;
+        const int v2 = acc[rt][4 * q + 2] + cr[2] + ct, v3 = acc[rt][4 * q + 3] + cr[3] + ct;
+        m = max(max(m, max(v0, v1)), max(v2, v3));
+      }
+      update = __any(m > s_low);
+    }
+    if (update) {
+      any_hit = true;
+      // the row terms are (re-)read through a pointer the optimiser cannot identify with pass 1's,
+      // or it keeps all 16 live across the branch and spills
+      const int* rterm2 = rterm_wave;
+      asm volatile("" : "+v"(rterm2));
+      int m = -1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4i cr = *(const v4i*)(rterm2 + rt * kTile + 8 * q + 4 * h);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * q + i;
           const int v = acc[rt][r] + cr[i] + ct;
-          if (__any(v > s_low)) {  // wave-uniform: this register holds a relevant similarity
-            const u32 rk = ((u32)v << 6) | jcode;
-            rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
-            rbest[rt][r] = umax(rbest[rt][r], rk);
-            if (FUSED) {
-              const u32 ck = ((u32)v << 6) | (u32)(63 - (rt * kTile + (r & 3) + 8 * (r >> 2)));
-              cs2 = umed3(cb, cs2, ck);
-              cb = umax(cb, ck);
-            }
+          m = max(m, v);
+          const u32 rk = ((u32)v << 6) | jcode;
+          rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
+          rbest[rt][r] = umax(rbest[rt][r], rk);
+          if (FUSED) {
+            const u32 ck = ((u32)v << 6) | (u32)(63 - (rt * kTile + (r & 3) + 8 * (r >> 2)));
+            cs2 = umed3(cb, cs2, ck);
+            cb = umax(cb, ck);
           }
         }
       }
+      dense[rt] = __any(m > s_low);
     }
   }
 #ifndef VC_EXP_NO_COLATOMIC
@@ -417,6 +448,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     colbest[j] = 0ull;
     colsecond[j] = 0u;
   }
+  if (FUSED)  // defaults for rows whose reduction round is skipped (ordered by the tile barriers)
+    for (int i = tid; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
   const int rbias = -49024 * d;
   int* crow6_wave = crow6 + wave * 64;
   const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
@@ -456,6 +489,9 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     if (lane < RT * kTile) my_rterm = 128 * a_rowsum[tile0 * kTile + lane] + rbias;
     if (lane < RT * kTile) crow6_wave[lane] = my_rterm;
     const u32 row_base = (u32)(tile0 * kTile);
+    bool dense[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) dense[rt] = false;
     v16i acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -486,11 +522,11 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
       if (!late) mfma_phase<KS, RT>(afrag, acc, slot, lane);
       const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
       const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, ejt, c, h, row_base, eth);
+      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, ejt, c, h, row_base, eth, dense);
       if (late) mfma_phase<KS, RT>(afrag, acc, slot, lane);
     }
     if (late)
-      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low);
+      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low, dense);
 #undef VC_TILE_HEAD
 
     // ---- row results of this pass ------------------------------------------------------
@@ -511,6 +547,11 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        // a round whose 16 rows never saw a relevant similarity keeps the (0, 0, -1) defaults
+        u32 seen = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) seen |= rbest[rt][8 * half + j];
+        if (FUSED && !__any(seen != 0)) continue;  // (the one-way API reports every row)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int r = 8 * half + j;
