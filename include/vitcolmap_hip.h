@@ -167,6 +167,18 @@ int vc_preprocess_u8(const uint8_t* images_bgr, int n_images, int h, int w, int 
                      int out_dtype, int layout, void* out, uint8_t* resized_bgr_or_null,
                      vc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * ViT glue (bf16): y = LayerNorm(x + residual) in one pass — the two memory-bound ops between
+ * the GEMMs of a DINOv2 block (the model behind reference vit_extractor.py:135-146).
+ * x, residual, y: [rows][C] bfloat16; gamma, beta: [C] bfloat16; statistics in float32.
+ * residual_or_null == NULL: plain LayerNorm.  sum_out_or_null (may alias neither input) receives
+ * x + residual rounded to bfloat16, i.e. the new residual stream.  C % 8 == 0, C <= 2048,
+ * all pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const void* gamma,
+                          const void* beta, float eps, int rows, int C, void* sum_out_or_null,
+                          void* y_out, vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

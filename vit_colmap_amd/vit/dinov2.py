@@ -211,10 +211,29 @@ class DinoV2(nn.Module):
         x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.interpolated_pos_embed(hp, wp)
         if self.register_tokens is not None:
             x = torch.cat([x[:, :1], self.register_tokens.expand(B, -1, -1), x[:, 1:]], dim=1)
-        for blk in self.blocks:
-            x = blk(x)
-        x = self.norm(x)
+        if x.is_cuda and x.dtype == torch.bfloat16 and all(b.folded for b in self.blocks) and not self.training:
+            x = self._blocks_fused(x.contiguous())
+        else:
+            for blk in self.blocks:
+                x = blk(x)
+            x = self.norm(x)
         return x[:, 1 + self.arch.registers:]
+
+    def _blocks_fused(self, x):
+        """bf16 GPU path: every residual add is fused with the LayerNorm that follows it
+        (csrc/vit_ops.hip), including the one that crosses into the next block / the final norm."""
+        from .hip_ops import add_layernorm
+
+        blocks = list(self.blocks)
+        _, h = add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, 1e-6)
+        for i, blk in enumerate(blocks):
+            a = blk.attn(h)
+            x, h = add_layernorm(a, x, blk.norm2.weight, blk.norm2.bias, 1e-6)
+            m = blk.mlp(h)
+            last = i + 1 == len(blocks)
+            nxt = self.norm if last else blocks[i + 1].norm1
+            x, h = add_layernorm(m, x, nxt.weight, nxt.bias, 1e-6, want_sum=not last)
+        return h
 
     def forward_features(self, image: torch.Tensor):
         """(B, 3, H, W) normalised image -> dict with 'x_norm_patchtokens', the key the reference
