@@ -166,6 +166,17 @@ inline int plan_slots(int ks, int n_pad) {
   return ns >= 2 ? (int)ns : 0;
 }
 
+#ifdef VC_EXP_STAMP
+// diagnostic build only: shader-clock stamp (the wait keeps s_memtime ordered with LDS traffic)
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
+
 __device__ inline void wg_barrier() {
   // LDS writes/atomics of this wave are complete before it arrives; LDS-DMA stays in flight
 #ifdef VC_EXP_NO_BARRIER
@@ -230,24 +241,27 @@ template <int KS>
 __device__ __forceinline__ void wait_tile(int wave, int younger) {
   constexpr int M = Producer<KS>::M;
   if (wave < Producer<KS>::NP) {
-    switch (younger) {
-      case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0 * M) : "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * M) : "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * M) : "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * M) : "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * M) : "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * M) : "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * M) : "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * M) : "memory"); break;
+#define VC_W(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * M) : "memory")
+    // binary decision tree: three scalar branches per call instead of a chain of eight
+    if (younger < 4) {
+      if (younger < 2) { if (younger == 0) VC_W(0); else VC_W(1); }
+      else             { if (younger == 2) VC_W(2); else VC_W(3); }
+    } else {
+      if (younger < 6) { if (younger == 4) VC_W(4); else VC_W(5); }
+      else             { if (younger == 6) VC_W(6); else VC_W(7); }
     }
+#undef VC_W
   }
 }
 
 // MFMA phase: similarity tiles of the wave's RT row tiles against one column tile.
 // acc = sum (a-128)(b-128) over k (C operand 0); the bias terms are added in the epilogue.
-template <int KS, int RT>
+// `mid()` runs after the first fragment group's MFMAs have been issued: the matrix pipe is busy for
+// the next ~128 cycles, which hides the issue cost of the LDS-DMA pieces placed there (in-kernel
+// stamps showed the producer waves' staging on the critical path when it sat right after the barrier).
+template <int KS, int RT, typename Mid>
 __device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&acc)[RT], const uint8_t* slot,
-                                           int lane) {
+                                           int lane, Mid mid) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -286,6 +300,7 @@ __device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&ac
 #endif
       }
     __builtin_amdgcn_sched_barrier(0);
+    if (g == 0) mid();
   }
 }
 
@@ -329,26 +344,39 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
   const u32 jcode = 63u - (u32)jt;
   u32 cb = 0, cs2 = 0;
   bool any_hit = false;
+  // Two regimes, chosen per row tile from what the previous column tile looked like (wave-uniform):
+  //   sparse: pass 1 computes the lane's largest similarity only (24 VALU); if some lane is
+  //           relevant, pass 2 recomputes the similarities and updates (and switches to dense);
+  //   dense : one pass that updates and tracks the maximum (SIFT-like descriptors sit at
+  //           cos ~0.64, right at the threshold: there almost every tile is relevant).
+  // Pass 1 runs for all row tiles first, with every LDS read of the row terms issued up front:
+  // measured with in-kernel stamps, the epilogue was LDS-latency-bound (890 cycles per tile for
+  // ~70 instructions) when each row tile waited for its own reads.
+  bool update[RT];
+  bool all_dense = true;
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    // Two regimes, chosen per row tile from what the previous column tile looked like (wave-uniform):
-    //   sparse: pass 1 computes the lane's largest similarity only (24 VALU); if some lane is
-    //           relevant, pass 2 recomputes the similarities and updates (and switches to dense);
-    //   dense : one pass that updates and tracks the maximum (SIFT-like descriptors sit at
-    //           cos ~0.64, right at the threshold: there almost every tile is relevant).
-    bool update = dense[rt];
-    if (!update) {
+  for (int rt = 0; rt < RT; ++rt) { update[rt] = dense[rt]; all_dense = all_dense && dense[rt]; }
+  if (!all_dense) {
+    v4i cr[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cr[rt][q] = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
       int m = -1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
-        const int v0 = acc[rt][4 * q + 0] + cr[0] + ct, v1 = acc[rt][4 * q + 1] + cr[1] + ct;
-        const int v2 = acc[rt][4 * q + 2] + cr[2] + ct, v3 = acc[rt][4 * q + 3] + cr[3] + ct;
+        const int v0 = acc[rt][4 * q + 0] + cr[rt][q][0] + ct, v1 = acc[rt][4 * q + 1] + cr[rt][q][1] + ct;
+        const int v2 = acc[rt][4 * q + 2] + cr[rt][q][2] + ct, v3 = acc[rt][4 * q + 3] + cr[rt][q][3] + ct;
         m = max(max(m, max(v0, v1)), max(v2, v3));
       }
-      update = __any(m > s_low);
+      update[rt] = update[rt] || __any(m > s_low);
     }
-    if (update) {
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (update[rt]) {
       any_hit = true;
       // the row terms are (re-)read through a pointer the optimiser cannot identify with pass 1's,
       // or it keeps all 16 live across the branch and spills
@@ -414,6 +442,9 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D
   int* wave_count = crow6 + kWaves * 64 + kWaves * kRowScratchBytes / 4;
 
+#ifdef VC_EXP_STAMP
+  const unsigned long long t_kernel_start = stamp();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,6 +460,21 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   const uint8_t* b_frags = prepared + (size_t)img_b * img_stride;
   const int32_t* a_rowsum = (const int32_t*)(a_frags + (size_t)n_tiles_img * KS * kFragBytes);
   const int32_t* b_rowsum = (const int32_t*)(b_frags + (size_t)n_tiles_img * KS * kFragBytes);
+
+  // Pass 0's A fragments and row sums depend only on the pair indices: issue them now so that
+  // their latency overlaps the (dependent) count lookups, the LDS initialisation and the first
+  // LDS-DMA pieces instead of following them.
+  v4i afrag[RT][KS];
+  {
+    const int tile0 = wave * RT;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+        afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
+  }
+  int rowsum0 = 0;
+  if (lane < RT * kTile) rowsum0 = a_rowsum[wave * RT * kTile + lane];
 
   constexpr int kRowsPerPass = kWaves * RT * kTile;
   const int n_ct = ceil_div(n2, kTile);  // column tiles of b that hold valid rows
@@ -473,21 +519,24 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
 
   for (int pass = 0; pass < n_pass; ++pass) {
     const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
-    // A fragments stay in registers for the whole pass (every tile index exists: tiles_of()).
-    v4i afrag[RT][KS];
+    // A fragments stay in registers for the whole pass (every tile index exists: tiles_of());
+    // pass 0's were requested at kernel entry.
     u32 rbest[RT][16], rsec[RT][16];
+    int rowsum = rowsum0;
+    if (pass > 0) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
-        afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
+        for (int kk = 0; kk < KS; ++kk)
+          afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
+      if (lane < RT * kTile) rowsum = a_rowsum[tile0 * kTile + lane];
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
-    }
     // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows)
-    int my_rterm = rbias;
-    if (lane < RT * kTile) my_rterm = 128 * a_rowsum[tile0 * kTile + lane] + rbias;
-    if (lane < RT * kTile) crow6_wave[lane] = my_rterm;
+    if (lane < RT * kTile) crow6_wave[lane] = 128 * rowsum + rbias;
     const u32 row_base = (u32)(tile0 * kTile);
     bool dense[RT];
 #pragma unroll
@@ -498,33 +547,60 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][r] = 0;
 
-    // one iteration = one column tile: wait for it, barrier, refill the slot freed by the
-    // previous iteration, then the two phases in the order of this wave's half
+    // one iteration = one column tile: wait for it, barrier, then the two phases in the order of
+    // this wave's half
 #define VC_TILE_HEAD()                                                                              \
     wait_tile<KS>(wave, prod_seq - cons_seq - 1);                                                   \
     wg_barrier();                                                                                   \
-    if (prod_seq < total) {                                                                         \
-      stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes,                                   \
-                     ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);                    \
-      ++prod_seq;                                                                                   \
-      if (++prod_jt == n_ct) prod_jt = 0;                                                           \
-      if (++prod_slot == ns) prod_slot = 0;                                                         \
-    }                                                                                               \
     const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;                               \
     if (++cons_slot == ns) cons_slot = 0;                                                           \
     ++cons_seq;
+    // refill of the slot freed by the previous iteration; legal anywhere after the barrier
+    auto produce = [&]() {
+      if (prod_seq < total) {
+        stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes,
+                       ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
+        ++prod_seq;
+        if (++prod_jt == n_ct) prod_jt = 0;
+        if (++prod_slot == ns) prod_slot = 0;
+      }
+    };
 
     // Staggered halves (late = waves 4-7): one loop, the epilogue shared, only the MFMA phase
     // placed before or after it.  The late half runs the epilogue of tile jt-1; for jt = 0 that
     // call is neutralised by an unreachable threshold (its accumulators are not defined yet).
+#ifdef VC_EXP_STAMP
+    unsigned long long sw = 0, sm = 0, se = 0, sm2 = 0;
+    const unsigned long long t_begin = stamp();
+    unsigned long long tp = t_begin;
+#endif
     for (int jt = 0; jt < n_ct; ++jt) {
       VC_TILE_HEAD()
-      if (!late) mfma_phase<KS, RT>(afrag, acc, slot, lane);
+#ifdef VC_EXP_STAMP
+      unsigned long long ta = stamp(); sw += ta - tp;
+#endif
+      if (!late) mfma_phase<KS, RT>(afrag, acc, slot, lane, produce);
+#ifdef VC_EXP_STAMP
+      unsigned long long tb = stamp(); sm += tb - ta;
+#endif
       const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
       const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
       epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, ejt, c, h, row_base, eth, dense);
-      if (late) mfma_phase<KS, RT>(afrag, acc, slot, lane);
+#ifdef VC_EXP_STAMP
+      unsigned long long tc = stamp(); se += tc - tb;
+#endif
+      if (late) mfma_phase<KS, RT>(afrag, acc, slot, lane, produce);
+#ifdef VC_EXP_STAMP
+      tp = stamp(); sm2 += tp - tc;
+#endif
     }
+#ifdef VC_EXP_STAMP
+    if (FUSED && lane == 0 && pass == 0) {
+      uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
+      dbg[0] = (uint32_t)sw; dbg[1] = (uint32_t)(sm + sm2); dbg[2] = (uint32_t)se;
+      dbg[3] = (uint32_t)(tp - t_begin); dbg[4] = (uint32_t)(t_begin - t_kernel_start);
+    }
+#endif
     if (late)
       epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low, dense);
 #undef VC_TILE_HEAD
@@ -639,6 +715,13 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     __syncthreads();
   }
   if (tid == 0) out_counts[p] = base;
+#ifdef VC_EXP_STAMP
+  if (lane == 0) {
+    const unsigned long long t_end = stamp();
+    uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
+    dbg[5] = (uint32_t)(t_end - t_kernel_start);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
