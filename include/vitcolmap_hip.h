@@ -179,6 +179,14 @@ int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const voi
                           const void* beta, float eps, int rows, int C, void* sum_out_or_null,
                           void* y_out, vc_stream_t stream);
 
+/*
+ * Multi-head self-attention forward, head_dim 64 (DINOv2 ViT-S/B/L): softmax(Q K^T / 8) V.
+ * qkv [batch][n_tokens][3][n_heads][64] bfloat16 (the fused qkv projection's output as it is),
+ * out [batch][n_tokens][n_heads*64] bfloat16 (what the output projection reads).  16-byte aligned.
+ */
+int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, void* out,
+                      vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

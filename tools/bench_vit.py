@@ -62,3 +62,10 @@ if os.environ.get("TUNE") == "1":
         print(f"TUNED gemm {name}: {t*1e3:.1f} us  {fl/t/1e9:.0f} TFLOP/s (tuning took {tt:.1f}s)")
 h = torch.randn(B * N, 1536, device=dev, dtype=torch.bfloat16)
 t = timeit(lambda: F.gelu(h)); print(f"gelu: {t*1e3:.1f} us")
+try:
+    from vit_colmap_amd.vit.hip_ops import attention
+    qkv_c = torch.randn(B, N, 3 * C, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: attention(qkv_c, H))
+    print(f"HIP attention: {t*1e3:.1f} us  {flops_attn/t/1e9:.0f} TFLOP/s")
+except Exception as e:
+    print("hip attention failed:", e)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "vc_quantize_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "vc_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "vc_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
 }

@@ -1,0 +1,241 @@
+// Flash-style multi-head self-attention forward for the DINOv2 blocks (head_dim 64, bf16), written
+// for 64-wide wavefronts and the gfx950 MFMA / LDS model.  Replaces the
+// `scaled_dot_product_attention` call inside the model behind reference
+// vit_colmap/features/vit_extractor.py:135-146 (torch.hub DINOv2 `forward_features`).
+//
+// Input  qkv [B][N][3][H][64] bf16 — exactly what the fused qkv GEMM writes, no permute/copy;
+// output out [B][N][H*64] bf16   — exactly what the projection GEMM reads.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+//   * swapped product: S^T = K Q^T (v_mfma_f32_32x32x16_bf16, A = K fragment from LDS, B = Q
+//     fragment kept in registers), so a lane holds 32 scores of ONE query (its partner lane,
+//     l ^ 32, the other 32 of the 64-key block): the row max / row sum are lane-local plus one
+//     cross-half exchange, no LDS round trip;
+//   * the f32 S^T accumulators, converted pairwise to bf16, ARE the B operand of the second
+//     product O^T = V^T P^T (accumulator tile as the next MFMA's operand: registers 8s..8s+7 are
+//     k-step s, whose k index maps to key 16s + 8(j>>2) + 4h + (j&3));
+//   * V stays row-major in LDS and is read with ds_read_b64_tr_b16 (hardware transpose): two reads
+//     give a lane the 8 keys of its k-step for its d column — no V^T copy anywhere;
+//   * K / V tiles of 64 keys are staged global -> registers -> LDS one block ahead (the loads are
+//     issued before the block's MFMAs, the LDS writes after them), double buffered, one barrier
+//     per block; both tiles are XOR-swizzled against bank conflicts (K: 16-byte slot ^ (key & 7)
+//     for the ds_read_b128 column slices; V: byte bit 6 ^ bit 1 of the key for the transposed reads);
+//   * online softmax in exp2 domain with the rescale skipped when no row maximum moved.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vitcolmap_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kHD = 64;        // head dim
+constexpr int kWavesA = 4;     // waves per workgroup
+constexpr int kQW = 32;        // queries per wave
+constexpr int kQB = kWavesA * kQW;  // 128 queries per workgroup
+constexpr int kKV = 64;        // keys per block
+constexpr int kTileBytes = kKV * kHD * 2;  // 8 KiB
+
+__device__ inline uint32_t k_off(int key, int slot) { return (uint32_t)key * 128u + (uint32_t)((slot ^ (key & 7)) << 4); }
+__device__ inline uint32_t v_off(int key, int byte_in_row) {
+  return (uint32_t)key * 128u + ((uint32_t)byte_in_row ^ (uint32_t)(((key >> 1) & 1) << 6));
+}
+
+__global__ __launch_bounds__(256, 3) void attention_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+                                                           int N, int H, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3][2][kTileBytes];  // ring slot x [K | V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q_row = blockIdx.x * kQB + wave * kQW + r;
+  const size_t tok_stride = (size_t)3 * H * kHD;  // elements between consecutive tokens
+  const __bf16* base = qkv + (size_t)b * N * tok_stride + (size_t)h * kHD;
+
+  // Q fragments (B operand): lane (query r, half hh) holds Q[q][16ks + 8hh .. +8]
+  v8bf qf[4];
+  {
+    const __bf16* qp = base + (size_t)min(q_row, N - 1) * tok_stride;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8bf*)(qp + 16 * ks + 8 * hh);
+  }
+
+  // K / V tiles (64 keys) go global -> LDS by LDS-DMA, two blocks ahead, into a ring of three
+  // slots.  A block is 16 pieces of 1 KiB (8 keys x 128 B); wave w issues pieces 4w..4w+3.  The
+  // LDS destination of a piece is lane-linear, so the bank swizzles are applied to the per-lane
+  // SOURCE address: LDS chunk c' of key k receives source chunk c' ^ (k & 7) (K) or
+  // c' ^ (((k >> 1) & 1) << 2) (V).  Issued from inline asm and waited for with a counted vmcnt
+  // (hipcc would drain them before every LDS read, and serialised the register-staged variant).
+  const int n_blk = (N + kKV - 1) / kKV;
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0][0][0]);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_block = [&](int blk, int slot) {
+    blk = min(blk, n_blk - 1);   // past the end: re-stage the last block into a slot nobody reads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pce = wave_u * 4 + i;
+      const int which = pce >> 3, kg = pce & 7;
+      const int krow = lane >> 3, cdst = lane & 7;
+      const int key = kg * 8 + krow;
+      const int csrc = which == 0 ? (cdst ^ krow) : (cdst ^ (((krow >> 1) & 1) << 2));
+      const int tok = min(blk * kKV + key, N - 1);
+      const __bf16* src = base + (size_t)tok * tok_stride + (size_t)(1 + which) * H * kHD + csrc * 8;
+      const uint32_t dst = lds0 + (uint32_t)slot * (2 * kTileBytes) + (uint32_t)which * kTileBytes + (uint32_t)kg * 1024u;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src), "s"(dst)
+          : "memory");
+    }
+  };
+  issue_block(0, 0);
+  issue_block(1, 1);
+
+  v16f acc_o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // transposed-read addressing: 16-lane group g, lane i of the group supplies row q = i>>2,
+  // columns 4p..4p+3 (p = i&3) of a 4-key x 16-d block
+  const int grp = lane >> 4, gi = lane & 15, tq = gi >> 2, tp = gi & 3;
+
+  int slot = 0;
+  for (int blk = 0; blk < n_blk; ++blk) {
+    // this wave's 4 pieces of block blk have landed when at most the 4 of block blk+1 are pending
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the slot read in the previous iteration is free now: refill it two blocks ahead
+    issue_block(blk + 2, slot == 0 ? 2 : slot - 1);
+    const int buf = slot;
+    const uint8_t* kt = lds[buf][0];
+    const uint8_t* vt = lds[buf][1];
+
+    // ---- S^T = K Q^T : two 32-key tiles -----------------------------------------------------
+    v16f acc_s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_s[t][i] = 0.f;
+      const int key = t * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const v8bf kf = *(const v8bf*)(kt + k_off(key, 2 * ks + hh));
+        acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc_s[t], 0, 0, 0);
+      }
+    }
+    // keys past the end of the sequence (last block only)
+    if (blk == n_blk - 1 && (N & (kKV - 1)) != 0) {
+      const int kv0 = blk * kKV;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kv0 + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (key >= N) acc_s[t][i] = -1e30f;
+        }
+    }
+
+    // ---- online softmax (exp2 domain); a lane and its partner (l ^ 32) share one query ------
+    float mloc = acc_s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, acc_s[t][i]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m_run, mloc);
+    if (!__all(m_new == m_run)) {  // some row maximum moved: rescale the running state
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
+      m_run = m_new;
+    }
+    const float mb = m_run * scale_log2e;
+    float lsum = 0.f;
+    v8bf pf[4];  // P^T as B operand: k-step s <- registers 8(s&1)..+7 of tile s>>1
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int t = s >> 1, r0 = 8 * (s & 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // one v_fma_f32 + one v_exp_f32 (exp2f() would add range scaling: 5 instructions)
+        const float pj = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[t][r0 + j], scale_log2e, -mb));
+        lsum += pj;
+        pf[s][j] = (__bf16)pj;
+      }
+    }
+    l_run += lsum;
+
+    // ---- O^T += V^T P^T : two 32-d tiles x four 16-key k-steps --------------------------------
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int dbase = 16 * (grp & 1) + 32 * dt;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kbase = (s >> 1) * 32 + 16 * (s & 1) + 4 * hh;   // keys of elements j = 0..3
+        const int key0 = kbase + tq, key1 = kbase + 8 + tq;        // ... and of j = 4..7
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(vt + v_off(key0, (dbase + 4 * tp) * 2)));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(vt + v_off(key1, (dbase + 4 * tp) * 2)));
+        v8bf vf;
+        *(v4s*)&vf = lo;
+        *((v4s*)&vf + 1) = hi;
+        acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], acc_o[dt], 0, 0, 0);
+      }
+    }
+
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two clamped refills before exiting
+
+  // ---- normalise and store: lane (query r, half hh) holds d = (i&3) + 8(i>>2) + 4hh + 32dt -------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_row < N) {
+    __bf16* op = out + ((size_t)b * N + q_row) * (size_t)H * kHD + (size_t)h * kHD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        v4bf o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)(acc_o[dt][4 * g4 + j] * inv);
+        *(v4bf*)(op + 32 * dt + 8 * g4 + 4 * hh) = o;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, void* out,
+                      vc_stream_t stream) {
+  if (!qkv || !out || batch < 0 || n_tokens <= 0 || n_heads <= 0) return VC_ERR_INVALID_ARG;
+  if (head_dim != kHD) return VC_ERR_UNSUPPORTED;
+  if ((((uintptr_t)qkv) | ((uintptr_t)out)) % 16 != 0) return VC_ERR_INVALID_ARG;
+  if (batch == 0) return VC_OK;
+  const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  const dim3 grid((n_tokens + kQB - 1) / kQB, batch * n_heads);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)out,
+                     n_tokens, n_heads, scale_log2e);
+  return vc::check_launch();
+}
+
+}  // extern "C"

@@ -73,6 +73,10 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
+        if x.is_cuda and x.dtype == torch.bfloat16 and C // self.num_heads == 64 and not self.training:
+            from .hip_ops import attention  # hand-written flash attention (csrc/attention.hip)
+
+            return self.proj(attention(self.qkv(x), self.num_heads))
         qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
         return self.proj(o.transpose(1, 2).reshape(B, N, C))
