@@ -78,18 +78,18 @@ class ViTExtractor(BaseExtractor):
         if projection is not None:
             self.set_projection(projection)
         self.timings = {"decode_s": 0.0, "gpu_s": 0.0, "db_s": 0.0, "images": 0}
-        if tune_gemm and self.device.type == "cuda":
-            # hipBLASLt's default heuristic is poor for the K = 384 shapes of ViT-S (fc1: 170 us vs
-            # 115 us tuned at 76 550 rows); TunableOp times the candidate kernels once per new GEMM
-            # shape (~1 s each, first batch only) and keeps the winner for the process lifetime.
-            import torch.cuda.tunable as tunable
-
-            tunable.enable(True)
-            tunable.set_max_tuning_duration(200)
-            tunable.set_max_tuning_iterations(20)
+        # hipBLASLt's default heuristic is poor for the K = 384 shapes of ViT-S (fc1: 170 us vs 115 us
+        # tuned at 76 550 rows); TunableOp times the candidate kernels once per new GEMM shape (~1 s
+        # each, first batch only).  It is switched on only around the ViT forward (`_tokens`), never
+        # process-wide: it aborts on some unrelated float32 batched GEMMs.
+        self.tune_gemm = bool(tune_gemm) and self.device.type == "cuda"
+        if self.tune_gemm:
             import os
             import tempfile
+            import torch.cuda.tunable as tunable
 
+            tunable.set_max_tuning_duration(200)
+            tunable.set_max_tuning_iterations(20)
             tunable.set_filename(os.path.join(tempfile.gettempdir(), f"vitcolmap_tunableop_{os.getuid()}.csv"))
         print("✓ ViT model ready")
 
@@ -122,7 +122,17 @@ class ViTExtractor(BaseExtractor):
         B, h, w, _ = images_bgr.shape
         hp, wp = h // PATCH, w // PATCH
         patches = hip_preprocess.preprocess(images_bgr, out_dtype=self.dtype, layout="patches")
-        tokens = self.model.forward_patch_tokens(patches, hp, wp).contiguous()
+        if self.tune_gemm:
+            import torch.cuda.tunable as tunable
+
+            was = tunable.is_enabled()
+            tunable.enable(True)
+            try:
+                tokens = self.model.forward_patch_tokens(patches, hp, wp).contiguous()
+            finally:
+                tunable.enable(was)
+        else:
+            tokens = self.model.forward_patch_tokens(patches, hp, wp).contiguous()
         return tokens, hp, wp
 
     @torch.inference_mode()
