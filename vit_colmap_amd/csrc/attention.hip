@@ -23,6 +23,7 @@
 //   * online softmax in exp2 domain with the rescale skipped when no row maximum moved.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vitcolmap_hip.h"
 #include "common.h"
@@ -47,22 +48,27 @@ __device__ inline uint32_t v_off(int key, int byte_in_row) {
   return (uint32_t)key * 128u + ((uint32_t)byte_in_row ^ (uint32_t)(((key >> 1) & 1) << 6));
 }
 
-__global__ __launch_bounds__(256, 3) void attention_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
-                                                           int N, int H, float scale_log2e) {
+// QT = 32-query tiles per wave.  QT = 2 reads every K / V fragment from LDS once for two MFMAs and
+// stages every K / V tile once for 256 instead of 128 query rows (at 2 waves per SIMD instead of 3).
+template <int QT>
+__global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const __bf16* __restrict__ qkv,
+                                                                           __bf16* __restrict__ out, int N, int H,
+                                                                           float scale_log2e) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[3][2][kTileBytes];  // ring slot x [K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int q_row = blockIdx.x * kQB + wave * kQW + r;
+  const int q_row0 = blockIdx.x * (kQB * QT) + wave * (kQW * QT) + r;   // + 32*qt
   const size_t tok_stride = (size_t)3 * H * kHD;  // elements between consecutive tokens
   const __bf16* base = qkv + (size_t)b * N * tok_stride + (size_t)h * kHD;
 
   // Q fragments (B operand): lane (query r, half hh) holds Q[q][16ks + 8hh .. +8]
-  v8bf qf[4];
-  {
-    const __bf16* qp = base + (size_t)min(q_row, N - 1) * tok_stride;
+  v8bf qf[QT][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8bf*)(qp + 16 * ks + 8 * hh);
+  for (int qt = 0; qt < QT; ++qt) {
+    const __bf16* qp = base + (size_t)min(q_row0 + 32 * qt, N - 1) * tok_stride;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const v8bf*)(qp + 16 * ks + 8 * hh);
   }
 
   // K / V tiles (64 keys) go global -> LDS by LDS-DMA, two blocks ahead, into a ring of three
@@ -101,12 +107,17 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const __bf16* __restr
   issue_block(0, 0);
   issue_block(1, 1);
 
-  v16f acc_o[2];
+  v16f acc_o[QT][2];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -1e30f;
+    l_run[qt] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc_o[dt][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_o[qt][dt][i] = 0.f;
+  }
 
   // transposed-read addressing: 16-lane group g, lane i of the group supplies row q = i>>2,
   // columns 4p..4p+3 (p = i&3) of a 4-key x 16-d block
@@ -119,69 +130,79 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const __bf16* __restr
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // the slot read in the previous iteration is free now: refill it two blocks ahead
     issue_block(blk + 2, slot == 0 ? 2 : slot - 1);
-    const int buf = slot;
-    const uint8_t* kt = lds[buf][0];
-    const uint8_t* vt = lds[buf][1];
+    const uint8_t* kt = lds[slot][0];
+    const uint8_t* vt = lds[slot][1];
 
-    // ---- S^T = K Q^T : two 32-key tiles -----------------------------------------------------
-    v16f acc_s[2];
+    // ---- S^T = K Q^T : two 32-key tiles (each K fragment feeds QT MFMAs) -----------------------
+    v16f acc_s[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_s[qt][t][i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc_s[t][i] = 0.f;
       const int key = t * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const v8bf kf = *(const v8bf*)(kt + k_off(key, 2 * ks + hh));
-        acc_s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc_s[t], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          acc_s[qt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qt][ks], acc_s[qt][t], 0, 0, 0);
       }
     }
     // keys past the end of the sequence (last block only)
     if (blk == n_blk - 1 && (N & (kKV - 1)) != 0) {
       const int kv0 = blk * kKV;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kv0 + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (key >= N) acc_s[t][i] = -1e30f;
-        }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kv0 + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (key >= N) acc_s[qt][t][i] = -1e30f;
+          }
     }
 
     // ---- online softmax (exp2 domain); a lane and its partner (l ^ 32) share one query ------
-    float mloc = acc_s[0][0];
+    v8bf pf[QT][4];  // P^T as B operand: k-step s <- registers 8(s&1)..+7 of tile s>>1
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int qt = 0; qt < QT; ++qt) {
+      float mloc = acc_s[qt][0][0];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, acc_s[t][i]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m_run, mloc);
-    if (!__all(m_new == m_run)) {  // some row maximum moved: rescale the running state
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-      l_run *= alpha;
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, acc_s[qt][t][i]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float m_new = fmaxf(m_run[qt], mloc);
+      if (!__all(m_new == m_run[qt])) {  // some row maximum moved: rescale the running state
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * scale_log2e);
+        l_run[qt] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
-      m_run = m_new;
-    }
-    const float mb = m_run * scale_log2e;
-    float lsum = 0.f;
-    v8bf pf[4];  // P^T as B operand: k-step s <- registers 8(s&1)..+7 of tile s>>1
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int t = s >> 1, r0 = 8 * (s & 1);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // one v_fma_f32 + one v_exp_f32 (exp2f() would add range scaling: 5 instructions)
-        const float pj = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[t][r0 + j], scale_log2e, -mb));
-        lsum += pj;
-        pf[s][j] = (__bf16)pj;
+          for (int i = 0; i < 16; ++i) acc_o[qt][dt][i] *= alpha;
+        m_run[qt] = m_new;
       }
+      const float mb = m_run[qt] * scale_log2e;
+      float lsum = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = s >> 1, r0 = 8 * (s & 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // one v_fma_f32 + one v_exp_f32 (exp2f() would add range scaling: 5 instructions)
+          const float pj = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[qt][t][r0 + j], scale_log2e, -mb));
+          lsum += pj;
+          pf[qt][s][j] = (__bf16)pj;
+        }
+      }
+      l_run[qt] += lsum;
     }
-    l_run += lsum;
 
-    // ---- O^T += V^T P^T : two 32-d tiles x four 16-key k-steps --------------------------------
+    // ---- O^T += V^T P^T : two 32-d tiles x four 16-key k-steps (each V fragment feeds QT MFMAs) --
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const int dbase = 16 * (grp & 1) + 32 * dt;
@@ -196,28 +217,33 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const __bf16* __restr
         v8bf vf;
         *(v4s*)&vf = lo;
         *((v4s*)&vf + 1) = hi;
-        acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], acc_o[dt], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          acc_o[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][s], acc_o[qt][dt], 0, 0, 0);
       }
     }
-
     slot = slot == 2 ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two clamped refills before exiting
 
   // ---- normalise and store: lane (query r, half hh) holds d = (i&3) + 8(i>>2) + 4hh + 32dt -------
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  if (q_row < N) {
-    __bf16* op = out + ((size_t)b * N + q_row) * (size_t)H * kHD + (size_t)h * kHD;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+    const float inv = 1.0f / l_tot;
+    const int q_row = q_row0 + 32 * qt;
+    if (q_row < N) {
+      __bf16* op = out + ((size_t)b * N + q_row) * (size_t)H * kHD + (size_t)h * kHD;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        v4bf o;
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (__bf16)(acc_o[dt][4 * g4 + j] * inv);
-        *(v4bf*)(op + 32 * dt + 8 * g4 + 4 * hh) = o;
-      }
+        for (int g4 = 0; g4 < 4; ++g4) {
+          v4bf o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (__bf16)(acc_o[qt][dt][4 * g4 + j] * inv);
+          *(v4bf*)(op + 32 * dt + 8 * g4 + 4 * hh) = o;
+        }
+    }
   }
 }
 
@@ -232,9 +258,16 @@ int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int
   if ((((uintptr_t)qkv) | ((uintptr_t)out)) % 16 != 0) return VC_ERR_INVALID_ARG;
   if (batch == 0) return VC_OK;
   const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-  const dim3 grid((n_tokens + kQB - 1) / kQB, batch * n_heads);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv, (__bf16*)out,
-                     n_tokens, n_heads, scale_log2e);
+  // two query tiles per wave once the sequence is long enough to fill the chip with 256-row blocks
+  int qt = n_tokens >= 512 ? 2 : 1;
+  if (const char* e = getenv("VITCOLMAP_ATTN_QT")) qt = atoi(e) == 1 ? 1 : 2;   // developer A/B switch
+  const dim3 grid((n_tokens + kQB * qt - 1) / (kQB * qt), batch * n_heads);
+  if (qt == 1)
+    hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv,
+                       (__bf16*)out, n_tokens, n_heads, scale_log2e);
+  else
+    hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv,
+                       (__bf16*)out, n_tokens, n_heads, scale_log2e);
   return vc::check_launch();
 }
 

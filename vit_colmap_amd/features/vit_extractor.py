@@ -90,7 +90,7 @@ class ViTExtractor(BaseExtractor):
 
             tunable.set_max_tuning_duration(200)
             tunable.set_max_tuning_iterations(20)
-            tunable.set_filename(os.path.join(tempfile.gettempdir(), f"vitcolmap_tunableop_{os.getuid()}.csv"))
+            tunable.set_filename(os.path.join(tempfile.gettempdir(), f"vitcolmap_tunableop_{os.getuid()}.csv"), True)  # one file per device
         print("✓ ViT model ready")
 
     # ------------------------------------------------------------------------------------------
