@@ -35,8 +35,7 @@ typedef unsigned int u32;
 constexpr int kWaves = 8;                    // waves per workgroup (2 per SIMD)
 constexpr int kThreads = kWaves * 64;        // 512
 constexpr int kTile = 32;                    // MFMA tile edge
-constexpr int kPassRows = kWaves * kTile;    // rows of image A covered per pass: 256
-constexpr int kMaxN = VC_MAX_KEYPOINTS;      // 2048 -> at most 64 column tiles (6-bit code)
+static_assert(VC_MAX_KEYPOINTS <= 64 * 32, "the row search packs the column-tile number into 6 bits");
 constexpr int kFragBytes = 1024;             // 64 lanes x 16 B
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
