@@ -272,6 +272,10 @@ __device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&ac
   constexpr int NG = KS / G;
   static_assert(KS % G == 0, "KS must be a multiple of the fragment group");
   const uint8_t* src = slot + lane * 16;
+#ifndef VC_NO_SETPRIO
+  // the wave that feeds the matrix pipe wins issue arbitration against its SIMD partner's epilogue
+  __builtin_amdgcn_s_setprio(1);
+#endif
   v4i bf[2][G];
 #pragma unroll
 #ifdef VC_EXP_NO_LDSREAD
@@ -301,6 +305,9 @@ __device__ __forceinline__ void mfma_phase(const v4i (&afrag)[RT][KS], v16i (&ac
     __builtin_amdgcn_sched_barrier(0);
     if (g == 0) mid();
   }
+#ifndef VC_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // Epilogue phase: top-2 updates for one column tile.
