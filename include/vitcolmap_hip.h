@@ -187,6 +187,49 @@ int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const voi
 int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, void* out,
                       vc_stream_t stream);
 
+/*
+ * Linear layer with fused epilogue (bf16 in, float32 accumulate on MFMA, bf16 out):
+ *   out = epi(x W^T + bias),  x [rows][k_in], weight [n_out][k_in] (torch.nn.Linear layout),
+ *   bias [n_out], out [rows][n_out].
+ * epilogue: VC_EPI_BIAS     out = x W^T + b                    (attn.qkv)
+ *           VC_EPI_GELU     out = gelu_erf(x W^T + b)          (mlp.fc1; exact GELU, erf to 1.5e-7)
+ *           VC_EPI_RESIDUAL out = residual + x W^T + b         (attn.proj, mlp.fc2: the block's
+ *                           residual-stream update; residual [rows][n_out], may alias out)
+ * The pre-activation is NOT rounded to bf16 before GELU / the residual add (one rounding less than
+ * the unfused sequence).  n_out % 128 == 0, k_in % 64 == 0, pointers 16-byte aligned,
+ * residual_or_null non-NULL exactly for VC_EPI_RESIDUAL.
+ * Replaces the nn.Linear / GELU / residual-add calls inside the hub model's blocks
+ * (reference vit_extractor.py:135-146).
+ */
+#define VC_EPI_BIAS 0
+#define VC_EPI_GELU 1
+#define VC_EPI_RESIDUAL 2
+int vc_linear_bf16(const void* x, const void* weight, const void* bias, const void* residual_or_null,
+                   void* out, int rows, int n_out, int k_in, int epilogue, vc_stream_t stream);
+
+/*
+ * The same linear layer for k_in == 384 (ViT-S: attn.qkv, attn.proj, mlp.fc1), "x-stationary":
+ * each wave keeps its 32 token rows in registers for the whole launch and only the weights stream
+ * (csrc/gemm.hip).  Optionally fuses the LayerNorm that precedes the layer in a pre-norm block:
+ *   out = epi(LayerNorm(x) W^T + b)   computed as   epi(((x - mean) rstd) (W diag(gamma))^T + (b + W beta)).
+ *
+ * vc_linear_xs_prepare (once per layer): weight [n_out][384] float32, bias [n_out] float32 or NULL,
+ *   ln_gamma / ln_beta [384] float32 or both NULL  ->  weight_tiled (vc_linear_xs_weight_bytes bytes:
+ *   bf16 in MFMA fragment order, piece (nb, ks) = features 32 nb..+32 x k 16 ks..+16, lane 32 h + r holds
+ *   W'[32 nb + r][16 ks + 8 h .. +8]) and bias_folded [n_out] float32.
+ * vc_linear_xs_bf16: x [rows][384] bf16, out [rows][n_out] bf16, epilogue as vc_linear_bf16;
+ *   fuse_layernorm != 0 normalises each x row first (two-pass float32 statistics, eps = ln_eps; the
+ *   weights must have been prepared with that LayerNorm's gamma / beta).  residual may alias out.
+ *   n_out % 32 == 0, n_out <= 4096, 16-byte aligned pointers.  Launches one persistent workgroup per CU.
+ */
+size_t vc_linear_xs_weight_bytes(int n_out, int k_in);
+int vc_linear_xs_prepare(const float* weight, const float* bias_or_null, const float* ln_gamma_or_null,
+                         const float* ln_beta_or_null, int n_out, int k_in, void* weight_tiled,
+                         float* bias_folded, vc_stream_t stream);
+int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias_folded,
+                      const void* residual_or_null, void* out, int rows, int n_out, int k_in, int epilogue,
+                      int fuse_layernorm, float ln_eps, vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,3 +86,78 @@ def test_attention_structured_values_catch_layout_errors():
     q, k, v = qb.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(B, N, H * 64)
     assert (out - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("rows,K,N", [(1531 * 2, 384, 1152), (300, 384, 384), (1531, 384, 1536), (1000, 1536, 384),
+                                      (1, 64, 128), (129, 768, 2304), (128, 128, 256)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_linear_matches_float32_reference(rows, K, N, epi):
+    """Hand-written bf16 GEMM + fused epilogue (through the C ABI) vs the float32 evaluation of the same bf16 data."""
+    from vit_colmap_amd.vit.hip_ops import linear
+
+    g = torch.Generator(device="cuda").manual_seed(rows + K + N + epi)
+    x = torch.randn(rows, K, device="cuda", generator=g).to(torch.bfloat16)
+    # asymmetric, non-uniform weights: a swapped fragment map or a transposed tile cannot pass
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5 * torch.linspace(0.5, 2.0, N, device="cuda")[:, None]).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    r = torch.randn(rows, N, device="cuda", generator=g).to(torch.bfloat16) if epi == 2 else None
+    out = linear(x, w, b, epi, r).float()
+    ref = x.float() @ w.float().t() + b.float()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + r.float()
+    # one rounding of a float32 result to bf16 (2^-9 relative) + float32 accumulation-order noise
+    err = (out - ref).abs()
+    tol = ref.abs() * 2 ** -8 + 2e-3
+    assert bool((err <= tol).all()), (float(err.max()), int((err > tol).sum()))
+
+
+def test_linear_rejects_unsupported_shapes():
+    from vit_colmap_amd import _lib
+    from vit_colmap_amd.vit.hip_ops import linear
+
+    x = torch.zeros(4, 100, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(128, 100, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(_lib.HipLibraryError):
+        linear(x, w, torch.zeros(128, device="cuda", dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("rows,N", [(1531 * 2, 1152), (300, 384), (1531 * 3, 1536), (1, 32), (255, 64), (257, 96),
+                                    (256 * 300, 384)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("ln", [False, True])
+def test_xs_linear_matches_float32_reference(rows, N, epi, ln):
+    """x-stationary K=384 GEMM (+ fused LayerNorm / epilogue) through the C ABI vs float32 on the same bf16 data."""
+    from vit_colmap_amd.vit.hip_ops import XsLinear
+
+    K = 384
+    g = torch.Generator(device="cuda").manual_seed(rows + N + epi + 7 * ln)
+    x = (torch.randn(rows, K, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5 * torch.linspace(0.5, 2.0, N, device="cuda")[:, None]
+    b = torch.randn(N, device="cuda", generator=g)
+    gam = 1 + 0.2 * torch.randn(K, device="cuda", generator=g) if ln else None
+    bet = 0.1 * torch.randn(K, device="cuda", generator=g) if ln else None
+    r = torch.randn(rows, N, device="cuda", generator=g).to(torch.bfloat16) if epi == 2 else None
+    lin = XsLinear(w, b, gam, bet, 1e-6)
+    out = lin(x, epi, r).float()
+    xin = x.float()
+    if ln:
+        xin = torch.nn.functional.layer_norm(xin, (K,), gam, bet, 1e-6)
+    ref = xin @ w.t() + b
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + r.float()
+    # operands are rounded to bf16 (x-hat and W diag(gamma): 2^-9 each, accumulated over K = 384 random-sign
+    # terms), the result once more
+    err = (out - ref).abs()
+    # (operand noise ~5e-3 rms at the widest rows, 5-sigma tails over millions of outputs, + half a bf16 ulp)
+    tol = ref.abs() * 2 ** -7 + 6e-2
+    assert bool((err <= tol).all()), (float(err.max()), int((err > tol).sum()))
+    assert float((err > ref.abs() * 2 ** -7 + 3e-2).float().mean()) < 1e-5
+    assert float((out - ref).norm() / ref.norm()) < 6e-3
+    if epi == 2:   # in place on the residual stream
+        r2 = r.clone()
+        lin(x, epi, r2, out=r2)
+        assert torch.equal(r2.float(), out)

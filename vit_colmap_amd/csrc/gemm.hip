@@ -1,0 +1,578 @@
+// bf16 linear layer with fused epilogue for the DINOv2 blocks (the model behind reference
+// vit_colmap/features/vit_extractor.py:135-146):  out = epi(x W^T + b)  with
+//   epi = identity (qkv), exact-erf GELU (fc1), or "+ residual" (attn.proj / fc2 — the residual
+//   stream update), so the activation and the residual add never make their own pass over HBM.
+//
+// x [M][K] bf16 (token rows), W [N][K] bf16 (torch Linear layout: one output feature per row),
+// out [M][N] bf16.  M is arbitrary (76 550 at 50 images x 1531 tokens), N % 128 == 0, K % 64 == 0.
+//
+// One workgroup = 4 waves = one 128 (tokens) x 128 (features) output tile; two workgroups per CU
+// (64 KiB of LDS, <= 128 VGPRs each) so that one tile's epilogue VALU work runs under the other's
+// MFMAs.  Per 64-deep K step both operand tiles (128 rows x 128 B) go global -> LDS by LDS-DMA
+// (1 KiB per wave instruction, destination lane-linear), double buffered one step ahead; the bank
+// swizzle (16-byte chunk ^ (row & 7), conflict-free for the ds_read_b128 column slices) is applied
+// to the per-lane SOURCE address.  The product is computed transposed,
+//   D^T[feature][token] = W_tile (A operand) x x_tile^T (B operand),  v_mfma_f32_16x16x32_bf16,
+// so a lane ends up with 4 CONSECUTIVE FEATURES of one token: bias, GELU and residual are applied
+// to 4-vectors and the bf16 result leaves as 8-byte stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vitcolmap_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;              // token rows per tile
+constexpr int BN = 128;              // output features per tile
+constexpr int BK = 64;               // K step: 64 bf16 = one 128-byte LDS row
+constexpr int kImg = 128 * 128;      // bytes of one operand image (128 rows x 128 B)
+constexpr int kStage = 2 * kImg;     // [x image | W image]
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
+
+// exact GELU, 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
+// with q = (1 - erf|z|) = poly(t) t exp(-z^2), t = 1 / (1 + p|z|):  gelu = max(x, 0) - 0.5 |x| q.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+  float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float zl = x * 0.84932180028801907f;   // x sqrt(log2(e) / 2):  exp(-x^2/2) = exp2(-zl^2)
+  const float e = __builtin_amdgcn_exp2f(-(zl * zl));
+  const float q = p * t * e;
+  return __builtin_fmaf(-0.5f * ax, q, __builtin_fmaxf(x, 0.0f));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W,
+                                                      const __bf16* __restrict__ bias,
+                                                      const __bf16* __restrict__ res, __bf16* __restrict__ out,
+                                                      int M, int N, int K, int n_tiles_n, int n_tiles) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2][kStage];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware tile order: the 8 XCDs take workgroups round-robin, so give each XCD a contiguous
+  // run of tiles (feature tiles fastest: the tiles an XCD works on at one time share x rows in its L2)
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int q = n_tiles >> 3, r = n_tiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / n_tiles_n, tn = tile - tm * n_tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- LDS-DMA staging: a stage is 32 pieces of 1 KiB (8 rows x 128 B); wave w issues x pieces
+  // 4w..4w+3 and W pieces 4w..4w+3.  Lane l fills LDS row (l >> 3), chunk (l & 7) of its piece with
+  // source chunk (l & 7) ^ (l >> 3)  [row & 7 == l >> 3 because pieces start at multiples of 8 rows].
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0][0]);
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  const __bf16* xsrc[4];
+  const __bf16* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + prow;
+    xsrc[i] = X + (size_t)min(m0 + row, M - 1) * K + pchunk * 8;
+    wsrc[i] = W + (size_t)(n0 + row) * K + pchunk * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const __bf16* src = (i < 4 ? xsrc[i] : wsrc[i - 4]) + kt * BK;
+      const uint32_t dst = lds0 + (uint32_t)buf * kStage + (uint32_t)(i >> 2) * kImg + (uint32_t)(wave * 4 + (i & 3)) * 1024u;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src), "s"(dst)
+          : "memory");
+    }
+  };
+
+  v4f acc[4][4];   // [feature block][token block]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: lane reads row (l & 15) of a 16-row block, 16-byte chunk 4 ks + (l >> 4)
+  const int fr = lane & 15, fq = lane >> 4;
+  uint32_t xoff[2], woff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ks * 4 + fq;
+    // rows of all 16-row blocks share (row & 7) == (fr & 7): one swizzled chunk offset per k-substep
+    xoff[ks] = (uint32_t)(wm * 64 + fr) * 128u + (uint32_t)((ch ^ (fr & 7)) << 4);
+    woff[ks] = (uint32_t)kImg + (uint32_t)(wn * 64 + fr) * 128u + (uint32_t)((ch ^ (fr & 7)) << 4);
+  }
+
+  const int nk = K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of step kt have landed; after the barrier everyone's have, and everyone
+    // has finished reading the other buffer (step kt-1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const uint8_t* st = lds[kt & 1];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v8bf wf[4], xf[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wf[a] = *(const v8bf*)(st + woff[ks] + a * (16 * 128));
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xf[b] = *(const v8bf*)(st + xoff[ks] + b * (16 * 128));
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane (token = l & 15 of block b, features 4 (l >> 4) .. +3 of block a) -------------
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int n = n0 + wn * 64 + a * 16 + fq * 4;
+    const v4bf bv = *(const v4bf*)(bias + n);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int m = m0 + wm * 64 + b * 16 + fr;
+      if (m < M) {
+        const size_t o = (size_t)m * N + n;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] + (float)bv[j];
+        if (EPI == EPI_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        }
+        if (EPI == EPI_RESIDUAL) {
+          const v4bf rv = *(const v4bf*)(res + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        }
+        v4bf ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = (__bf16)v[j];
+        *(v4bf*)(out + o) = ov;
+      }
+    }
+  }
+}
+
+
+// =====================================================================================================
+// x-stationary kernel for K = 384 (every Linear of ViT-S that reads the 384-wide residual stream or the
+// attention output: qkv, proj, fc1).  The staged kernel above moves (128 + 128) x K bytes through
+// L2 -> LDS per 128 x 128 tile and is bound by that traffic (measured ~10 TB/s aggregate at 30 % MFMA
+// utilisation).  Here a wave keeps ITS 32 token rows resident in registers as MFMA B fragments for the
+// whole launch (24 k-steps x 4 VGPRs = 96 VGPRs) and only W streams, once per 256-row workgroup:
+//   * W is pre-tiled on the host into fragment order (vc_linear_xs_prepare): piece (nb, ks) is the 1 KiB
+//     A operand of v_mfma_f32_32x32x16_bf16 for features 32 nb .. +32, k 16 ks .. +16, so a stage
+//     (one 32-feature block, 24 pieces) is 24 perfectly coalesced LDS-DMA instructions and a fragment
+//     read is ds_read_b128 at lane x 16 (conflict free, no swizzle);
+//   * 8 waves x 32 rows = 256 token rows per workgroup, one persistent workgroup per CU; the
+//     (row tile, feature block) stages are split evenly over the grid in row-tile-major order, so a
+//     workgroup reloads its x rows at most a few times and the grid finishes together (no tile-count
+//     quantisation: 14 400 stages over 256 CUs at fc1);
+//   * ring of 4 stages (96 KiB), filled 3 stages ahead, one barrier per stage (24 MFMAs per wave);
+//   * the two waves of a SIMD run in anti-phase: waves 0-3 do MFMA(i) then epilogue(i), waves 4-7
+//     epilogue(i-1) then MFMA(i), so the epilogue VALU work (bias, exact GELU, residual, bf16 pack)
+//     runs under the partner wave's MFMAs;
+//   * LayerNorm is fused into the x load: a lane and its partner (l ^ 32) hold one whole row, the
+//     statistics are two-pass float32 in registers, gamma is folded into W and beta into the bias by
+//     the prepare step, so the normalised activations never exist in memory;
+//   * D^T orientation (features on registers, token on the lane); two v_permlane32_swap per packed
+//     register pair give each lane 16 consecutive features -> 2 x 16-byte stores.
+constexpr int XK = 384;
+constexpr int XKS = XK / 16;                 // 24 k-steps of v_mfma_f32_32x32x16_bf16
+constexpr int XStage = XKS * 1024;           // 24 KiB: one 32-feature block of W in fragment order
+constexpr int XNS = 3;                       // ring slots
+constexpr int XPF = XNS - 1;                 // stages in flight
+constexpr int XMaxN = 4096;                  // bias staging area (floats)
+constexpr int XRows = 256;                   // token rows per workgroup (8 waves x 32)
+constexpr int XChunk = 32 * 128;             // x staging: 32 rows x 64 k (128-byte rows), per wave, double buffered
+constexpr int XOffBias = XNS * XStage;
+constexpr int XOffStage = XOffBias + XMaxN * 4;
+constexpr int XLds = XOffStage + 8 * 2 * XChunk;   // 72 + 16 + 64 = 152 KiB
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+template <int EPI, bool LN>
+__global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X, const uint8_t* __restrict__ Wp,
+                                                    const float* __restrict__ biasf, const __bf16* res,
+                                                    __bf16* out, int M, int N, int n_nb, int n_stages, float eps) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[XLds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool roleB = wave >= 4;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int s0 = (int)((long long)n_stages * bid / G), s1 = (int)((long long)n_stages * (bid + 1) / G);
+  const int n = s1 - s0;
+  if (n <= 0) return;
+
+  float* bias_l = (float*)(lds + XOffBias);
+  for (int i = tid; i < N; i += 512) bias_l[i] = biasf[i];   // visible after the first stage barrier
+
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0]);
+  // ---- producer: wave w issues pieces 3w..3w+2 of every stage ------------------------------------
+  int inb = s0 % n_nb, islot = 0, ileft = n;   // feature block / ring slot / stages left to issue
+  auto issue = [&]() {
+    const uint8_t* src = Wp + (size_t)inb * XStage + (size_t)(wave * 3) * 1024 + lane * 16;
+    const uint32_t dst = lds0 + (uint32_t)islot * XStage + (uint32_t)(wave * 3) * 1024u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src + i * 1024), "s"(dst + (uint32_t)i * 1024u)
+          : "memory");
+    }
+    // past the end the last stage is staged again into a slot nobody reads (keeps the vmcnt counts uniform)
+    if (ileft > 1) { --ileft; inb = inb + 1 == n_nb ? 0 : inb + 1; }
+    islot = islot + 1 == XNS ? 0 : islot + 1;
+  };
+#pragma unroll
+  for (int j = 0; j < XPF; ++j) issue();
+
+  // ---- x rows of this wave as B fragments ---------------------------------------------------------
+  // Fragment-shaped global loads (32 rows x 32 B per instruction) run at ~5 B/clk/CU, so the rows come
+  // in whole 128-byte lines by LDS-DMA into a wave-private, double-buffered staging area (32 rows x 64 k
+  // per chunk, 4 pieces of 8 rows) and are read back as fragments; the bank swizzle (chunk ^ ((row >> 1) & 7),
+  // conflict free for the 32-row column slices) is applied to the per-lane source address.
+  v8bf xf[XKS];
+  auto load_x = [&](int mt) {
+    const uint32_t sbase = lds0 + (uint32_t)XOffStage + (uint32_t)wave * (2 * XChunk);
+    const int prow = lane >> 3;
+    const uint8_t* xsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = 8 * p + prow;
+      const int m = min(mt * XRows + wave * 32 + row, M - 1);
+      xsrc[p] = (const uint8_t*)X + (size_t)m * (XK * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    auto stage_chunk = [&](int c) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(xsrc[p] + c * 128), "s"(sbase + (uint32_t)(c & 1) * XChunk + (uint32_t)p * 1024u)
+            : "memory");
+      }
+    };
+    const uint8_t* sp = lds + XOffStage + wave * (2 * XChunk) + r * 128;
+    const int fsw = (r >> 1) & 7;
+    stage_chunk(0);
+    stage_chunk(1);
+#pragma unroll
+    for (int c = 0; c < XK / 64; ++c) {
+      if (c + 1 < XK / 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        xf[4 * c + k4] = *(const v8bf*)(sp + (c & 1) * XChunk + (((2 * k4 + h) ^ fsw) << 4));
+      if (c + 2 < XK / 64) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this buffer are done before it is refilled
+        stage_chunk(c + 2);
+      }
+    }
+    if (LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)xf[ks][j];
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / XK);
+      // opaque touch: the three passes re-convert from the packed bf16 registers instead of keeping 192 floats live
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)xf[ks][j] - mean; q += d * d; }
+      q += __shfl_xor(q, 32);
+      const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / XK) + eps);
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[ks][j] = (__bf16)(((float)xf[ks][j] - mean) * rstd);
+    }
+  };
+
+  // ---- epilogue of one 32 (features) x 32 (tokens) block.  MFMA side: lane = token r, half h, register
+  // 4g + j = feature 8g + 4h + j.  A row-per-lane global access (32 rows per instruction) is issue-bound in
+  // the texture path, so both the residual read and the result write go through a wave-private transposer
+  // in the (idle) x staging area — [32 tokens][64 B], 16-byte chunk ^ ((token >> 2) & 3), conflict free both
+  // ways — and touch memory as lane -> (token l >> 2 (+16), 16-byte chunk l & 3): 16 rows x 64 contiguous
+  // bytes per instruction.  DS operations of one wave execute in order, so no wait separates write and read.
+  // results leave through a raw buffer store: rows past M fall outside num_records and are dropped by the
+  // hardware, so every epilogue issues exactly two store instructions (the vmcnt bookkeeping below counts them)
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)M * N * 2), 0x00020000);
+  uint8_t* const tr_out = lds + XOffStage + wave * (2 * XChunk);
+  uint8_t* const tr_res = tr_out + 2048;
+  const int crow = lane >> 2, cch = lane & 3;
+  const int rsw = (r >> 2) & 3;
+  v4u resq[2];
+  auto load_res = [&](int m_base, int nb) {
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        resq[q] = *(const v4u*)(res + (size_t)min(m_base + crow + 16 * q, M - 1) * N + nb * 32 + cch * 8);
+    }
+  };
+  auto epilogue = [&](const v16f& a, int m_base, int nb) {
+#ifdef VC_XS_NOEPI
+    if (a[0] == 12345.678f && a[7] == 1.25f) out[nb] = (__bf16)a[1];
+    return;
+#endif
+    v4bf resv[4];
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = crow + 16 * q;
+        *(v4u*)(tr_res + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4)) = resq[q];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) resv[g] = *(const v4bf*)(tr_res + r * 64 + ((g ^ rsw) << 4) + 8 * h);
+    }
+    uint32_t p[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = a[4 * g + j];
+        if (EPI == EPI_GELU) v[j] = gelu_erf(v[j]);
+        if (EPI == EPI_RESIDUAL) v[j] += (float)resv[g][j];
+      }
+      typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+      const v2bf lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+      p[2 * g] = *(const uint32_t*)&lo;
+      p[2 * g + 1] = *(const uint32_t*)&hi;
+    }
+    // exchange with the partner lane (l ^ 32): h = 0 ends with features 0..15, h = 1 with 16..31
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // i = 0,1: group 0 <-> group 2;  i = 2,3: group 1 <-> group 3
+      const auto sw = __builtin_amdgcn_permlane32_swap(p[i], p[i + 4], false, false);
+      p[i] = sw[0];
+      p[i + 4] = sw[1];
+    }
+    *(v4u*)(tr_out + r * 64 + (((2 * h) ^ rsw) << 4)) = (v4u){p[0], p[1], p[4], p[5]};
+    *(v4u*)(tr_out + r * 64 + (((2 * h + 1) ^ rsw) << 4)) = (v4u){p[2], p[3], p[6], p[7]};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = crow + 16 * q;
+      const v4u o = *(const v4u*)(tr_out + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4));
+#ifdef VC_XS_NOSTORE
+      if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u)
+#endif
+      __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, (int)(((size_t)(m_base + row) * N + nb * 32 + cch * 8) * 2), 0, 0);
+    }
+  };
+
+  v16f acc;
+  int mt_cur = -1, slot = 0;
+  int pm_base = 0, pnb = 0;                     // waves 4-7: the block whose epilogue is pending
+  int mt = s0 / n_nb, nb = s0 - mt * n_nb;
+  for (int i = 0; i < n; ++i) {
+    // This wave's pieces of stage i (issued in iteration i-2) have landed once only operations issued after
+    // them are pending.  From iteration 2 on those are at least: the result stores of one epilogue (2), the
+    // pieces of stage i+1 (3) and two rounds of residual loads (2 each) — waves 4-7, whose epilogue precedes
+    // the refill, have exactly that many; waves 0-3 two stores more.  Counting them keeps a wave from
+    // stalling on the write acknowledgement of stores it issued a stage ago.
+    if (i >= 2) {
+      if (EPI == EPI_RESIDUAL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (roleB && i > 0) epilogue(acc, pm_base, pnb);
+    issue();                                    // stage i + 2 into the slot read during iteration i - 1
+    const int m_base = mt * XRows + wave * 32;
+#ifdef VC_XS_NOXRELOAD
+    if (mt_cur < 0) { load_x(mt); mt_cur = mt; }
+#else
+    if (mt != mt_cur) { load_x(mt); mt_cur = mt; }
+#endif
+    load_res(m_base, nb);
+    const uint8_t* st = lds + slot * XStage + lane * 16;
+    {
+      // the bias is the accumulator's initial value: register 4g + j <- bias[32 nb + 8g + 4h + j]
+      const float* bl = bias_l + nb * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v4f bv = *(const v4f*)(bl + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * g + j] = bv[j];
+      }
+    }
+    __builtin_amdgcn_s_setprio(1);
+    {
+      // W fragments are read XRD k-steps ahead of the MFMA that consumes them (LDS latency ~ 4 MFMAs);
+      // sched_barrier pins the order, the compiler places the counted lgkmcnt waits
+      constexpr int XRD = 8;
+      v8bf wf[XKS];
+#pragma unroll
+      for (int ks = 0; ks < XRD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks) {
+#ifdef VC_XS_NOMFMA
+        acc[ks & 15] += (float)wf[ks][0] * (float)xf[ks][0];
+#else
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
+#endif
+        if (ks + XRD < XKS) wf[ks + XRD] = *(const v8bf*)(st + (ks + XRD) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (!roleB) epilogue(acc, m_base, nb);
+    else { pm_base = m_base; pnb = nb; }
+    slot = slot + 1 == XNS ? 0 : slot + 1;
+    if (++nb == n_nb) { nb = 0; ++mt; }
+  }
+  if (roleB) epilogue(acc, pm_base, pnb);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped refills before the LDS is released
+}
+
+// W [N][K] float32 (+ optional LayerNorm gamma / beta [K] folded in) -> fragment-ordered bf16 + float32 bias.
+__global__ __launch_bounds__(256) void xs_prepare_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int N, __bf16* __restrict__ Wp, float* __restrict__ biasf) {
+  // one wave per output feature n
+  const int lane = threadIdx.x & 63;
+  const int nfeat = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (nfeat >= N) return;
+  const int nb = nfeat >> 5, rr = nfeat & 31;
+  float dot = 0.f;
+  for (int k = lane; k < XK; k += 64) {
+    const float w = W[(size_t)nfeat * XK + k];
+    const float wg = gamma ? w * gamma[k] : w;
+    if (beta) dot += w * beta[k];
+    const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
+    Wp[(((size_t)nb * XKS + ks) * 64 + hh * 32 + rr) * 8 + j] = (__bf16)wg;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  if (lane == 0) biasf[nfeat] = (b ? b[nfeat] : 0.f) + dot;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_linear_bf16(const void* x, const void* weight, const void* bias, const void* residual_or_null, void* out,
+                   int rows, int n_out, int k_in, int epilogue, vc_stream_t stream) {
+  if (!x || !weight || !bias || !out || rows < 0 || n_out <= 0 || k_in <= 0) return VC_ERR_INVALID_ARG;
+  if (epilogue < EPI_BIAS || epilogue > EPI_RESIDUAL) return VC_ERR_INVALID_ARG;
+  if ((epilogue == EPI_RESIDUAL) != (residual_or_null != nullptr)) return VC_ERR_INVALID_ARG;
+  if (n_out % BN != 0 || k_in % BK != 0) return VC_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)weight) | ((uintptr_t)bias) | ((uintptr_t)residual_or_null) | ((uintptr_t)out)) % 16 != 0)
+    return VC_ERR_INVALID_ARG;
+  if (rows == 0) return VC_OK;
+  const int tiles_m = (rows + BM - 1) / BM, tiles_n = n_out / BN;
+  const long long nt = (long long)tiles_m * tiles_n;
+  if (nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)nt), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16 *px = (const __bf16*)x, *pw = (const __bf16*)weight, *pb = (const __bf16*)bias,
+               *pr = (const __bf16*)residual_or_null;
+  __bf16* po = (__bf16*)out;
+  switch (epilogue) {
+    case EPI_BIAS:
+      hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+      break;
+    case EPI_GELU:
+      hipLaunchKernelGGL(gemm_kernel<EPI_GELU>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+      break;
+    default:
+      hipLaunchKernelGGL(gemm_kernel<EPI_RESIDUAL>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+      break;
+  }
+  return vc::check_launch();
+}
+
+
+size_t vc_linear_xs_weight_bytes(int n_out, int k_in) {
+  if (n_out <= 0 || k_in != XK || n_out % 32 != 0) return 0;
+  return (size_t)n_out * XK * 2;
+}
+
+int vc_linear_xs_prepare(const float* weight, const float* bias_or_null, const float* ln_gamma_or_null,
+                         const float* ln_beta_or_null, int n_out, int k_in, void* weight_tiled, float* bias_folded,
+                         vc_stream_t stream) {
+  if (!weight || !weight_tiled || !bias_folded || n_out <= 0) return VC_ERR_INVALID_ARG;
+  if (k_in != XK || n_out % 32 != 0 || n_out > XMaxN) return VC_ERR_UNSUPPORTED;
+  if ((ln_gamma_or_null == nullptr) != (ln_beta_or_null == nullptr)) return VC_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(xs_prepare_kernel, dim3((n_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, weight, bias_or_null,
+                     ln_gamma_or_null, ln_beta_or_null, n_out, (__bf16*)weight_tiled, bias_folded);
+  return vc::check_launch();
+}
+
+int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias_folded, const void* residual_or_null,
+                      void* out, int rows, int n_out, int k_in, int epilogue, int fuse_layernorm, float ln_eps,
+                      vc_stream_t stream) {
+  if (!x || !weight_tiled || !bias_folded || !out || rows < 0 || n_out <= 0) return VC_ERR_INVALID_ARG;
+  if (epilogue < EPI_BIAS || epilogue > EPI_RESIDUAL) return VC_ERR_INVALID_ARG;
+  if ((epilogue == EPI_RESIDUAL) != (residual_or_null != nullptr)) return VC_ERR_INVALID_ARG;
+  if (k_in != XK || n_out % 32 != 0 || n_out > XMaxN) return VC_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)weight_tiled) | ((uintptr_t)bias_folded) | ((uintptr_t)residual_or_null) | ((uintptr_t)out)) % 16 != 0)
+    return VC_ERR_INVALID_ARG;
+  if (rows == 0) return VC_OK;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return vc::fail(hipErrorInvalidDevice);
+  const int n_nb = n_out / 32;
+  const long long stages = (long long)((rows + XRows - 1) / XRows) * n_nb;
+  if (stages > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(stages < cus ? stages : cus)), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const __bf16 *px = (const __bf16*)x, *pr = (const __bf16*)residual_or_null;
+  const uint8_t* pw = (const uint8_t*)weight_tiled;
+  __bf16* po = (__bf16*)out;
+#define VC_XS_LAUNCH(E, L) \
+  hipLaunchKernelGGL((xs_kernel<E, L>), grid, block, 0, s, px, pw, bias_folded, pr, po, rows, n_out, n_nb, (int)stages, ln_eps)
+  const bool ln = fuse_layernorm != 0;
+  if (epilogue == EPI_BIAS) { if (ln) VC_XS_LAUNCH(EPI_BIAS, true); else VC_XS_LAUNCH(EPI_BIAS, false); }
+  else if (epilogue == EPI_GELU) { if (ln) VC_XS_LAUNCH(EPI_GELU, true); else VC_XS_LAUNCH(EPI_GELU, false); }
+  else { if (ln) VC_XS_LAUNCH(EPI_RESIDUAL, true); else VC_XS_LAUNCH(EPI_RESIDUAL, false); }
+#undef VC_XS_LAUNCH
+  return vc::check_launch();
+}
+
+}  // extern "C"

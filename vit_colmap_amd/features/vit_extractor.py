@@ -72,6 +72,9 @@ class ViTExtractor(BaseExtractor):
         self.model = self._load_model()
         self.model.eval()
         self.model.fold_layerscale()
+        if self.device.type == "cuda" and self.dtype == torch.bfloat16:
+            self.model.to(device=self.device)
+            self.model.prepare_hip()      # GEMM operands from the float32 parameters (csrc/gemm.hip), ViT-S only
         self.model.to(device=self.device, dtype=self.dtype)
         self.patch_size = PATCH
         self.descriptor_projection = None  # vit_extractor.py:82

@@ -148,6 +148,7 @@ class DinoV2(nn.Module):
         self.blocks = nn.ModuleList([Block(arch) for _ in range(arch.depth)])
         self.norm = nn.LayerNorm(d, eps=1e-6)
         self._pos_cache = {}
+        self._hip = None    # per-block XsLinear operands (prepare_hip), False when the architecture is not covered
 
     # -- weights --------------------------------------------------------------------------------
     @torch.no_grad()
@@ -223,11 +224,49 @@ class DinoV2(nn.Module):
             x = self.norm(x)
         return x[:, 1 + self.arch.registers:]
 
+    @torch.no_grad()
+    def prepare_hip(self):
+        """Build the x-stationary GEMM operands (csrc/gemm.hip) of every block from the CURRENT parameters:
+        qkv with norm1 folded in, proj, fc1 with norm2 folded in.  Call it while the parameters are still
+        float32 (after fold_layerscale, on the GPU) so gamma is folded before the one rounding to bf16;
+        `_blocks_fused` calls it lazily otherwise.  Only the 384-wide MLP models (ViT-S) are covered."""
+        from .hip_ops import XsLinear
+
+        self._hip = False
+        if self.arch.dim != 384 or self.arch.ffn != "mlp" or not all(b.folded for b in self.blocks):
+            return self
+        if not self.pos_embed.is_cuda:
+            raise RuntimeError("prepare_hip needs the model on the GPU")
+        self._hip = [dict(
+            qkv=XsLinear(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, b.norm1.eps),
+            proj=XsLinear(b.attn.proj.weight, b.attn.proj.bias),
+            fc1=XsLinear(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm2.weight, b.norm2.bias, b.norm2.eps),
+        ) for b in self.blocks]
+        return self
+
+    def _blocks_hip(self, x):
+        """ViT-S bf16 path on the hand-written GEMMs: LayerNorm lives in the x load of qkv / fc1, GELU and
+        both residual adds in GEMM epilogues; per block 5 kernels and no standalone elementwise pass."""
+        from . import hip_ops as ops
+
+        for blk, hw in zip(self.blocks, self._hip):
+            a = ops.attention(hw["qkv"](x), blk.attn.num_heads)           # LN1 + qkv, then flash attention
+            hw["proj"](a, ops.EPI_RESIDUAL, residual=x, out=x)            # x += proj(a)
+            hdn = hw["fc1"](x, ops.EPI_GELU)                              # gelu(fc1(LN2 x))
+            fc2 = blk.mlp.fc2
+            ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=x, out=x)   # x += fc2(hdn)
+        _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return h
+
     def _blocks_fused(self, x):
         """bf16 GPU path: every residual add is fused with the LayerNorm that follows it
         (csrc/vit_ops.hip), including the one that crosses into the next block / the final norm."""
         from .hip_ops import add_layernorm
 
+        if getattr(self, "_hip", None) is None:
+            self.prepare_hip()
+        if self._hip:
+            return self._blocks_hip(x)
         blocks = list(self.blocks)
         _, h = add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, 1e-6)
         for i, blk in enumerate(blocks):

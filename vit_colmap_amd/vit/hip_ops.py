@@ -1,4 +1,4 @@
-"""Torch front end of csrc/vit_ops.hip: LayerNorm fused with the preceding residual add (bf16)."""
+"""Torch front end of the ViT kernels (csrc/vit_ops.hip, attention.hip, gemm.hip): bf16, through the C ABI."""
 import torch
 
 from .. import _lib
@@ -30,3 +30,66 @@ def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
     _lib.check(lib.vc_attention_bf16(_lib.ptr(qkv), B, N, n_heads, hd, _lib.ptr(out), _lib.stream_ptr()),
                "vc_attention_bf16")
     return out
+
+
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL = 0, 1, 2
+
+
+def linear_supported(weight: torch.Tensor) -> bool:
+    """Shapes csrc/gemm.hip covers (every Linear of DINOv2 ViT-S/B/L/g does)."""
+    n, k = weight.shape
+    return n % 128 == 0 and k % 64 == 0
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, epilogue: int = EPI_BIAS,
+           residual=None, out=None) -> torch.Tensor:
+    """out = epi(x W^T + b) (csrc/gemm.hip): EPI_GELU applies the exact GELU, EPI_RESIDUAL adds `residual`."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert weight.dtype == torch.bfloat16 and weight.is_contiguous() and bias.dtype == torch.bfloat16
+    n, k = weight.shape
+    assert x.shape[-1] == k
+    rows = x.numel() // k
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (n,), dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.numel() == rows * n
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == torch.bfloat16 and residual.is_contiguous()
+    lib = _lib.load()
+    _lib.check(lib.vc_linear_bf16(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out),
+                                  rows, n, k, epilogue, _lib.stream_ptr()), "vc_linear_bf16")
+    return out
+
+
+class XsLinear:
+    """A Linear with k_in == 384 prepared for csrc/gemm.hip's x-stationary kernel (optionally with the
+    preceding LayerNorm folded in).  Built once from float32 parameters; call with bf16 activations."""
+
+    def __init__(self, weight: torch.Tensor, bias, ln_weight=None, ln_bias=None, ln_eps: float = 1e-6):
+        lib = _lib.load()
+        n, k = weight.shape
+        nbytes = lib.vc_linear_xs_weight_bytes(n, k)
+        if nbytes == 0:
+            raise _lib.HipLibraryError(f"vc_linear_xs: unsupported shape {n}x{k}")
+        dev = weight.device
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        g = None if ln_weight is None else ln_weight.detach().float().contiguous()
+        be = None if ln_bias is None else ln_bias.detach().float().contiguous()
+        self.n, self.k, self.ln, self.eps = n, k, g is not None, float(ln_eps)
+        self.wp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.bias = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.vc_linear_xs_prepare(_lib.ptr(w), _lib.ptr(b), _lib.ptr(g), _lib.ptr(be), n, k, _lib.ptr(self.wp),
+                                            _lib.ptr(self.bias), _lib.stream_ptr()), "vc_linear_xs_prepare")
+
+    def __call__(self, x: torch.Tensor, epilogue: int = EPI_BIAS, residual=None, out=None) -> torch.Tensor:
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == self.k
+        rows = x.numel() // self.k
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (self.n,), dtype=torch.bfloat16, device=x.device)
+        if residual is not None:
+            assert residual.shape == out.shape and residual.dtype == torch.bfloat16 and residual.is_contiguous()
+        lib = _lib.load()
+        _lib.check(lib.vc_linear_xs_bf16(_lib.ptr(x), _lib.ptr(self.wp), _lib.ptr(self.bias), _lib.ptr(residual),
+                                         _lib.ptr(out), rows, self.n, self.k, epilogue, int(self.ln), self.eps,
+                                         _lib.stream_ptr()), "vc_linear_xs_bf16")
+        return out
