@@ -50,6 +50,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return __builtin_fmaf(-0.5f * ax, q, __builtin_fmaxf(x, 0.0f));
 }
 
+// The same on a pair of values with 2-wide packed float32 operations (v_pk_fma_f32 / v_pk_mul_f32):
+// beside a partner wave that owns the matrix pipe, a lone wave's VALU stream is issue-bound, and a packed
+// instruction does twice the work per issue slot.  Only rcp / exp2 / abs / max stay one value at a time.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t gelu_erf2(v2f_t x) {
+  const v2f_t ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  const v2f_t one = {1.0f, 1.0f};
+  const v2f_t den = __builtin_elementwise_fma(ax, (v2f_t){0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f}, one);
+  const v2f_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  v2f_t p = __builtin_elementwise_fma(t, (v2f_t){1.061405429f, 1.061405429f}, (v2f_t){-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, (v2f_t){1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, (v2f_t){-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, (v2f_t){0.254829592f, 0.254829592f});
+  const v2f_t zl = x * (v2f_t){0.84932180028801907f, 0.84932180028801907f};
+  const v2f_t z2 = zl * zl;
+  const v2f_t e = {__builtin_amdgcn_exp2f(-z2[0]), __builtin_amdgcn_exp2f(-z2[1])};
+  const v2f_t q = p * t * e;
+  const v2f_t pos = {__builtin_fmaxf(x[0], 0.0f), __builtin_fmaxf(x[1], 0.0f)};
+  return __builtin_elementwise_fma(ax * (v2f_t){-0.5f, -0.5f}, q, pos);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W,
                                                       const __bf16* __restrict__ bias,
@@ -189,15 +210,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
 //     (row tile, feature block) stages are split evenly over the grid in row-tile-major order, so a
 //     workgroup reloads its x rows at most a few times and the grid finishes together (no tile-count
 //     quantisation: 14 400 stages over 256 CUs at fc1);
-//   * ring of 4 stages (96 KiB), filled 3 stages ahead, one barrier per stage (24 MFMAs per wave);
-//   * the two waves of a SIMD run in anti-phase: waves 0-3 do MFMA(i) then epilogue(i), waves 4-7
-//     epilogue(i-1) then MFMA(i), so the epilogue VALU work (bias, exact GELU, residual, bf16 pack)
-//     runs under the partner wave's MFMAs;
+//   * ring of 3 stages (72 KiB), filled 2 stages ahead, one barrier per stage (24 MFMAs per wave);
+//   * all 8 waves run the same stream: the epilogue of block i-1 (exact GELU, residual, bf16 pack,
+//     transpose, store) is cut into slices issued between the 24 MFMAs of block i (see the epilogue
+//     comment for why the alternative — partner waves in anti-phase — serialises on this hardware);
 //   * LayerNorm is fused into the x load: a lane and its partner (l ^ 32) hold one whole row, the
 //     statistics are two-pass float32 in registers, gamma is folded into W and beta into the bias by
-//     the prepare step, so the normalised activations never exist in memory;
-//   * D^T orientation (features on registers, token on the lane); two v_permlane32_swap per packed
-//     register pair give each lane 16 consecutive features -> 2 x 16-byte stores.
+//     the prepare step, so the normalised activations never exist in memory; the bias is the
+//     accumulator's initial value;
+//   * D^T orientation (features on registers, token on the lane); v_permlane32_swap + a wave-private
+//     LDS transposer turn a block into 16 rows x 64 contiguous bytes per store instruction.
+// Measured (76 550 rows, 1x MI355X): qkv+LN 100 us, proj+residual 46 us, fc1+LN+GELU 156 us; ablations
+// (tools/xs_variants.sh): MFMA + ring alone 64 / 32 / 80 us, the x reloads ~10 us, stores ~10-20 us.
 constexpr int XK = 384;
 constexpr int XKS = XK / 16;                 // 24 k-steps of v_mfma_f32_32x32x16_bf16
 constexpr int XStage = XKS * 1024;           // 24 KiB: one 32-feature block of W in fragment order
@@ -220,7 +244,6 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   __shared__ __attribute__((aligned(1024))) uint8_t lds[XLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool roleB = wave >= 4;
   const int r = lane & 31, h = lane >> 5;
 
   const int G = gridDim.x, bid = blockIdx.x;
@@ -258,76 +281,79 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   for (int j = 0; j < XPF; ++j) issue();
 
   // ---- x rows of this wave as B fragments ---------------------------------------------------------
-  // Fragment-shaped global loads (32 rows x 32 B per instruction) run at ~5 B/clk/CU, so the rows come
-  // in whole 128-byte lines by LDS-DMA into a wave-private, double-buffered staging area (32 rows x 64 k
-  // per chunk, 4 pieces of 8 rows) and are read back as fragments; the bank swizzle (chunk ^ ((row >> 1) & 7),
-  // conflict free for the 32-row column slices) is applied to the per-lane source address.
+  // Fragment-shaped global loads (32 rows x 32 B per instruction) run at ~5 B/clk/CU, and a staged copy
+  // through LDS-DMA is limited by the bytes the staging area lets a wave keep in flight.  So the 32 rows
+  // are fetched in whole 128-byte lines straight into registers — 24 loads of 8 rows x 128 B, all in
+  // flight at once (the registers that will hold the fragments are the landing zone) — and then turned
+  // into fragments 64 k at a time through a 4 KiB wave-private LDS transposer ([32 rows][128 B], 16-byte
+  // chunk ^ ((row >> 1) & 7): conflict free for the 8-row writes and the 32-row column-slice reads).
+  // DS operations of one wave execute in order, so the transposer needs no waits between chunks.
   v8bf xf[XKS];
-  auto load_x = [&](int mt) {
-    const uint32_t sbase = lds0 + (uint32_t)XOffStage + (uint32_t)wave * (2 * XChunk);
-    const int prow = lane >> 3;
-    const uint8_t* xsrc[4];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int prow = lane >> 3;
+  auto x_issue = [&](int mt) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int row = 8 * p + prow;
-      const int m = min(mt * XRows + wave * 32 + row, M - 1);
-      xsrc[p] = (const uint8_t*)X + (size_t)m * (XK * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-    }
-    auto stage_chunk = [&](int c) {
+      const int m = min(mt * XRows + wave * 32 + 8 * p + prow, M - 1);
+      const uint8_t* src = (const uint8_t*)X + (size_t)m * (XK * 2) + (lane & 7) * 16;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        uint32_t keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(xsrc[p] + c * 128), "s"(sbase + (uint32_t)(c & 1) * XChunk + (uint32_t)p * 1024u)
-            : "memory");
-      }
-    };
-    const uint8_t* sp = lds + XOffStage + wave * (2 * XChunk) + r * 128;
+      for (int c = 0; c < XK / 64; ++c) *(v4u*)&xf[4 * c + p] = *(const v4u*)(src + c * 128);   // raw lines land in xf itself
+    }
+  };
+  auto x_finish = [&]() {
+    uint8_t* const tp = lds + XOffStage + wave * (2 * XChunk);
     const int fsw = (r >> 1) & 7;
-    stage_chunk(0);
-    stage_chunk(1);
 #pragma unroll
     for (int c = 0; c < XK / 64; ++c) {
-      if (c + 1 < XK / 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = 8 * p + prow;
+        *(v4u*)(tp + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) = *(const v4u*)&xf[4 * c + p];
+      }
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4)
-        xf[4 * c + k4] = *(const v8bf*)(sp + (c & 1) * XChunk + (((2 * k4 + h) ^ fsw) << 4));
-      if (c + 2 < XK / 64) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this buffer are done before it is refilled
-        stage_chunk(c + 2);
-      }
+        xf[4 * c + k4] = *(const v8bf*)(tp + r * 128 + (((2 * k4 + h) ^ fsw) << 4));
     }
     if (LN) {
-      float s = 0.f;
+      // two-pass float32 statistics with packed (2-wide) VALU ops; the passes re-expand the bf16 pairs
+      // (shift / mask) instead of keeping 192 floats live
+      auto expand = [](uint32_t u) { return (v2f){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
+      v2f s2 = {0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < XKS; ++ks)
+      for (int ks = 0; ks < XKS; ++ks) {
+        const v4u u = *(const v4u*)&xf[ks];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)xf[ks][j];
-      s += __shfl_xor(s, 32);
-      const float mean = s * (1.0f / XK);
-      // opaque touch: the three passes re-convert from the packed bf16 registers instead of keeping 192 floats live
+        for (int j = 0; j < 4; ++j) s2 += expand(u[j]);
+      }
+      float sum = s2[0] + s2[1];
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.0f / XK);
+      const v2f mean2 = {mean, mean};
 #pragma unroll
       for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
-      float q = 0.f;
+      v2f q2 = {0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < XKS; ++ks)
+      for (int ks = 0; ks < XKS; ++ks) {
+        const v4u u = *(const v4u*)&xf[ks];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)xf[ks][j] - mean; q += d * d; }
+        for (int j = 0; j < 4; ++j) { const v2f d = expand(u[j]) - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
+      }
+      float q = q2[0] + q2[1];
       q += __shfl_xor(q, 32);
       const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / XK) + eps);
+      const v2f rstd2 = {rstd, rstd};
 #pragma unroll
       for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
 #pragma unroll
-      for (int ks = 0; ks < XKS; ++ks)
+      for (int ks = 0; ks < XKS; ++ks) {
+        const v4u u = *(const v4u*)&xf[ks];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xf[ks][j] = (__bf16)(((float)xf[ks][j] - mean) * rstd);
+        for (int j = 0; j < 4; ++j) {
+          const v2f y = (expand(u[j]) - mean2) * rstd2;
+          xf[ks][2 * j] = (__bf16)y[0];
+          xf[ks][2 * j + 1] = (__bf16)y[1];
+        }
+      }
     }
   };
 
@@ -337,8 +363,13 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   // in the (idle) x staging area — [32 tokens][64 B], 16-byte chunk ^ ((token >> 2) & 3), conflict free both
   // ways — and touch memory as lane -> (token l >> 2 (+16), 16-byte chunk l & 3): 16 rows x 64 contiguous
   // bytes per instruction.  DS operations of one wave execute in order, so no wait separates write and read.
-  // results leave through a raw buffer store: rows past M fall outside num_records and are dropped by the
-  // hardware, so every epilogue issues exactly two store instructions (the vmcnt bookkeeping below counts them)
+  // Results leave through a raw buffer store: rows past M fall outside num_records and are dropped by the
+  // hardware, so every epilogue issues exactly two store instructions (the vmcnt bookkeeping below counts them).
+  //
+  // The epilogue of block i-1 is cut into 24 slices that are issued BETWEEN the 24 MFMAs of block i, in the
+  // same wave: back-to-back MFMAs of one wave hold the SIMD's vector issue port while they wait for the
+  // matrix pipe, so a partner wave's VALU-only epilogue makes no progress beside them (measured: the two
+  // waves of a SIMD ran serialised); an instruction stream that alternates MFMA and VALU shares the port.
   const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)M * N * 2), 0x00020000);
   uint8_t* const tr_out = lds + XOffStage + wave * (2 * XChunk);
   uint8_t* const tr_res = tr_out + 2048;
@@ -352,82 +383,127 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
         resq[q] = *(const v4u*)(res + (size_t)min(m_base + crow + 16 * q, M - 1) * N + nb * 32 + cch * 8);
     }
   };
-  auto epilogue = [&](const v16f& a, int m_base, int nb) {
-#ifdef VC_XS_NOEPI
-    if (a[0] == 12345.678f && a[7] == 1.25f) out[nb] = (__bf16)a[1];
-    return;
-#endif
-    v4bf resv[4];
+  // state that flows from slice to slice
+  v16f pa;          // the pending block's accumulators
+  float ev[16];     // ... after GELU / residual
+  uint32_t ep[8];   // ... packed to bf16 pairs
+  v4u eo[2];        // ... transposed for the store
+  int pm_base = 0, pnb = 0;
+  auto res_to_lds = [&]() {   // the pending block's residual (loaded an iteration ago) enters the transposer
     if (EPI == EPI_RESIDUAL) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int row = crow + 16 * q;
         *(v4u*)(tr_res + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4)) = resq[q];
       }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) resv[g] = *(const v4bf*)(tr_res + r * 64 + ((g ^ rsw) << 4) + 8 * h);
     }
-    uint32_t p[8];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = a[4 * g + j];
-        if (EPI == EPI_GELU) v[j] = gelu_erf(v[j]);
-        if (EPI == EPI_RESIDUAL) v[j] += (float)resv[g][j];
-      }
-      typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-      const v2bf lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
-      p[2 * g] = *(const uint32_t*)&lo;
-      p[2 * g + 1] = *(const uint32_t*)&hi;
-    }
-    // exchange with the partner lane (l ^ 32): h = 0 ends with features 0..15, h = 1 with 16..31
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // i = 0,1: group 0 <-> group 2;  i = 2,3: group 1 <-> group 3
-      const auto sw = __builtin_amdgcn_permlane32_swap(p[i], p[i + 4], false, false);
-      p[i] = sw[0];
-      p[i + 4] = sw[1];
-    }
-    *(v4u*)(tr_out + r * 64 + (((2 * h) ^ rsw) << 4)) = (v4u){p[0], p[1], p[4], p[5]};
-    *(v4u*)(tr_out + r * 64 + (((2 * h + 1) ^ rsw) << 4)) = (v4u){p[2], p[3], p[6], p[7]};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = crow + 16 * q;
-      const v4u o = *(const v4u*)(tr_out + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4));
-#ifdef VC_XS_NOSTORE
-      if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u)
+  };
+  auto slice = [&](int sl) {
+#ifdef VC_XS_NOEPI
+    if (sl == 23 && pa[0] == 12345.678f && pa[7] == 1.25f) out[pnb] = (__bf16)pa[1];
+    return;
 #endif
-      __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, (int)(((size_t)(m_base + row) * N + nb * 32 + cch * 8) * 2), 0, 0);
+    if (sl < 8) {                       // values 2 sl, 2 sl + 1
+      const int j0 = 2 * sl;
+      if (EPI == EPI_GELU) {
+        const v2f_t y = gelu_erf2((v2f_t){pa[j0], pa[j0 + 1]});
+        ev[j0] = y[0];
+        ev[j0 + 1] = y[1];
+      } else if (EPI == EPI_RESIDUAL) {
+        if ((sl & 1) == 0) {            // one 8-byte read serves values 4g .. 4g + 3
+          const int g = sl >> 1;
+          const v4bf rv = *(const v4bf*)(tr_res + r * 64 + ((g ^ rsw) << 4) + 8 * h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ev[4 * g + j] = pa[4 * g + j] + (float)rv[j];
+        }
+      } else {
+        ev[j0] = pa[j0];
+        ev[j0 + 1] = pa[j0 + 1];
+      }
+    } else if (sl < 12) {               // pack group g
+      const int g = sl - 8;
+      typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+      const v2bf lo = {(__bf16)ev[4 * g], (__bf16)ev[4 * g + 1]}, hi = {(__bf16)ev[4 * g + 2], (__bf16)ev[4 * g + 3]};
+      ep[2 * g] = *(const uint32_t*)&lo;
+      ep[2 * g + 1] = *(const uint32_t*)&hi;
+    } else if (sl == 12) {
+      // exchange with the partner lane (l ^ 32): h = 0 ends with features 0..15, h = 1 with 16..31
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {     // i = 0,1: group 0 <-> group 2;  i = 2,3: group 1 <-> group 3
+        const auto sw = __builtin_amdgcn_permlane32_swap(ep[i], ep[i + 4], false, false);
+        ep[i] = sw[0];
+        ep[i + 4] = sw[1];
+      }
+    } else if (sl == 13) {
+      *(v4u*)(tr_out + r * 64 + (((2 * h) ^ rsw) << 4)) = (v4u){ep[0], ep[1], ep[4], ep[5]};
+      *(v4u*)(tr_out + r * 64 + (((2 * h + 1) ^ rsw) << 4)) = (v4u){ep[2], ep[3], ep[6], ep[7]};
+    } else if (sl == 15) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = crow + 16 * q;
+        eo[q] = *(const v4u*)(tr_out + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4));
+      }
+    } else if (sl == 19) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = crow + 16 * q;
+#ifdef VC_XS_NOSTORE
+        if (eo[q][0] == 0x12345678u && eo[q][3] == 0x9abcdef0u)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(eo[q], out_rs, (int)(((size_t)(pm_base + row) * N + pnb * 32 + cch * 8) * 2), 0, 0);
+      }
     }
   };
 
+#ifdef VC_XS_STAMP
+  // diagnostic build only: per-wave cycle totals of the loop phases, written over the start of `out`
+  // after the last real store (tools/stamp_xs.py); no output value is computed from them
+  uint32_t st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t st_t0 = __builtin_amdgcn_s_memtime();
+  uint64_t st_prev = st_t0;
+#define XS_STAMP(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); st_c[k] += (uint32_t)(t_ - st_prev); st_prev = t_; }
+#else
+#define XS_STAMP(k)
+#endif
   v16f acc;
   int mt_cur = -1, slot = 0;
-  int pm_base = 0, pnb = 0;                     // waves 4-7: the block whose epilogue is pending
   int mt = s0 / n_nb, nb = s0 - mt * n_nb;
   for (int i = 0; i < n; ++i) {
     // This wave's pieces of stage i (issued in iteration i-2) have landed once only operations issued after
-    // them are pending.  From iteration 2 on those are at least: the result stores of one epilogue (2), the
-    // pieces of stage i+1 (3) and two rounds of residual loads (2 each) — waves 4-7, whose epilogue precedes
-    // the refill, have exactly that many; waves 0-3 two stores more.  Counting them keeps a wave from
-    // stalling on the write acknowledgement of stores it issued a stage ago.
-    if (i >= 2) {
-      if (EPI == EPI_RESIDUAL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    // them are pending: per iteration a wave issues 3 pieces, then (residual epilogue) 2 loads, then the 2
+    // result stores of the pending block — 7 (+4) from iteration 3 on, fewer while the pipeline fills.
+    // Counting them keeps a wave from stalling on the write acknowledgement of its latest stores.
+    if (i >= 3) {
+      if (EPI == EPI_RESIDUAL) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    } else if (i == 2) {
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     }
+    XS_STAMP(0)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (roleB && i > 0) epilogue(acc, pm_base, pnb);
+    XS_STAMP(1)
+    const bool pending = i > 0;
+    if (pending) res_to_lds();
+#ifdef VC_XS_NOXRELOAD
+    const bool reload = mt_cur < 0;
+#else
+    const bool reload = mt != mt_cur;
+#endif
     issue();                                    // stage i + 2 into the slot read during iteration i - 1
     const int m_base = mt * XRows + wave * 32;
-#ifdef VC_XS_NOXRELOAD
-    if (mt_cur < 0) { load_x(mt); mt_cur = mt; }
-#else
-    if (mt != mt_cur) { load_x(mt); mt_cur = mt; }
-#endif
+    if (reload) {
+      // new row tile: the pending block cannot ride under this block's MFMAs (its x loads come first)
+      x_issue(mt);
+      if (pending) {
+#pragma unroll
+        for (int sl = 0; sl < XKS; ++sl) slice(sl);
+      }
+      x_finish();
+      mt_cur = mt;
+    }
+    XS_STAMP(2)
     load_res(m_base, nb);
     const uint8_t* st = lds + slot * XStage + lane * 16;
     {
@@ -440,34 +516,53 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
         for (int j = 0; j < 4; ++j) acc[4 * g + j] = bv[j];
       }
     }
-    __builtin_amdgcn_s_setprio(1);
     {
       // W fragments are read XRD k-steps ahead of the MFMA that consumes them (LDS latency ~ 4 MFMAs);
-      // sched_barrier pins the order, the compiler places the counted lgkmcnt waits
+      // sched_barrier pins [MFMA, fragment read, epilogue slice] per k-step, the compiler places the waits
       constexpr int XRD = 8;
       v8bf wf[XKS];
 #pragma unroll
       for (int ks = 0; ks < XRD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
       __builtin_amdgcn_sched_barrier(0);
+      if (pending && !reload) {
 #pragma unroll
-      for (int ks = 0; ks < XKS; ++ks) {
-#ifdef VC_XS_NOMFMA
-        acc[ks & 15] += (float)wf[ks][0] * (float)xf[ks][0];
-#else
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
-#endif
-        if (ks + XRD < XKS) wf[ks + XRD] = *(const v8bf*)(st + (ks + XRD) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < XKS; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
+          if (ks + XRD < XKS) wf[ks + XRD] = *(const v8bf*)(st + (ks + XRD) * 1024);
+          slice(ks);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
+          if (ks + XRD < XKS) wf[ks + XRD] = *(const v8bf*)(st + (ks + XRD) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    __builtin_amdgcn_s_setprio(0);
-    if (!roleB) epilogue(acc, m_base, nb);
-    else { pm_base = m_base; pnb = nb; }
+    XS_STAMP(3)
+    pa = acc;
+    pm_base = m_base;
+    pnb = nb;
     slot = slot + 1 == XNS ? 0 : slot + 1;
     if (++nb == n_nb) { nb = 0; ++mt; }
   }
-  if (roleB) epilogue(acc, pm_base, pnb);
+  // the last block's epilogue has no MFMAs to ride under
+  res_to_lds();
+#pragma unroll
+  for (int sl = 0; sl < XKS; ++sl) slice(sl);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped refills before the LDS is released
+#ifdef VC_XS_STAMP
+  XS_STAMP(6)
+  st_c[7] = (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0);
+  if (lane < 8) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = lane == k ? st_c[k] : v;
+    ((uint32_t*)out)[(bid * 8 + wave) * 8 + lane] = v;
+  }
+#endif
 }
 
 // W [N][K] float32 (+ optional LayerNorm gamma / beta [K] folded in) -> fragment-ordered bf16 + float32 bias.
