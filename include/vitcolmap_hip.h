@@ -157,6 +157,9 @@ int vc_quantize_u8(const float* in, uint8_t* out, size_t n, vc_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 #define VC_LAYOUT_NCHW 0    /* out [n][3][out_h][out_w]                                        */
 #define VC_LAYOUT_PATCHES 1 /* out [n][(out_h/14)*(out_w/14)][3*14*14], element (c, dy, dx)    */
+#define VC_LAYOUT_PATCHES_PAD 2 /* the same with rows padded to VC_PATCH_K_PADDED elements, zeros in the
+                                   padding: the A operand of vc_patch_embed_bf16                  */
+#define VC_PATCH_K_PADDED 640
 
 /*
  * images_bgr [n_images][h][w][3] uint8 -> model input (float32 or bfloat16, VC_DTYPE_*).
@@ -229,6 +232,18 @@ int vc_linear_xs_prepare(const float* weight, const float* bias_or_null, const f
 int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias_folded,
                       const void* residual_or_null, void* out, int rows, int n_out, int k_in, int epilogue,
                       int fuse_layernorm, float ln_eps, vc_stream_t stream);
+
+/*
+ * DINOv2 patch embedding + position embedding in one GEMM (the conv 14x14 / 14 of the hub model as a
+ * matrix product over padded patches):
+ *   out[b][1 + t][:] = patches[b][t][:] W^T + bias + pos_embed[1 + t][:]      t = 0 .. tokens-1
+ * patches [n_images][tokens][k_in] bf16 (vc_preprocess_u8 with VC_LAYOUT_PATCHES_PAD, k_in = VC_PATCH_K_PADDED),
+ * weight [n_out][k_in] bf16 (conv weight flattened (c, dy, dx), zero padded), bias [n_out] bf16,
+ * pos_embed [1 + tokens][n_out] bf16 (already interpolated to this grid), out [n_images][1 + tokens][n_out] bf16.
+ * Row 0 of every image (the class token + pos_embed[0]) is NOT written here.  n_out % 128 == 0, k_in % 64 == 0.
+ */
+int vc_patch_embed_bf16(const void* patches, const void* weight, const void* bias, const void* pos_embed,
+                        void* out, int n_images, int tokens, int n_out, int k_in, vc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -161,3 +161,28 @@ def test_xs_linear_matches_float32_reference(rows, N, epi, ln):
         r2 = r.clone()
         lin(x, epi, r2, out=r2)
         assert torch.equal(r2.float(), out)
+
+
+def test_patch_embed_gemm_matches_reference_and_padded_preprocess():
+    """vc_patch_embed_bf16 (patch embedding + bias + position embedding, class-token row skipped) vs float32 on the
+    same bf16 data, and the padded patch layout of the preprocessing kernel vs the unpadded one."""
+    from vit_colmap_amd.features import hip_preprocess
+    from vit_colmap_amd.vit.hip_ops import patch_embed
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.randint(0, 256, (3, 70, 98, 3), device="cuda", generator=g, dtype=torch.uint8)
+    p0 = hip_preprocess.preprocess(img, layout="patches")
+    p1 = hip_preprocess.preprocess(img, layout="patches_pad")
+    assert p1.shape == (3, 35, 640) and torch.equal(p1[..., :588], p0) and not bool(p1[..., 588:].any())
+    B, T, C = 3, 35, 384
+    w = torch.zeros(C, 640, device="cuda")
+    w[:, :588] = torch.randn(C, 588, device="cuda", generator=g) / 588 ** 0.5 * torch.linspace(0.5, 2, C, device="cuda")[:, None]
+    w = w.to(torch.bfloat16)
+    b = torch.randn(C, device="cuda", generator=g).to(torch.bfloat16)
+    pos = torch.randn(1, T + 1, C, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.full((B, T + 1, C), 7.0, device="cuda", dtype=torch.bfloat16)
+    patch_embed(p1, w, b, pos, out)
+    assert bool((out[:, 0] == 7.0).all())                       # class-token rows untouched
+    ref = p1.float() @ w.float().t() + b.float() + pos[0, 1:].float()
+    err = (out[:, 1:].float() - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -8 + 1e-2).all()), float(err.max())

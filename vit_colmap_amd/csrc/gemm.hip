@@ -33,7 +33,7 @@ constexpr int BK = 64;               // K step: 64 bf16 = one 128-byte LDS row
 constexpr int kImg = 128 * 128;      // bytes of one operand image (128 rows x 128 B)
 constexpr int kStage = 2 * kImg;     // [x image | W image]
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESIDUAL = 2, EPI_PATCH = 3 };
 
 // exact GELU, 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
 // with q = (1 - erf|z|) = poly(t) t exp(-z^2), t = 1 / (1 + p|z|):  gelu = max(x, 0) - 0.5 |x| q.
@@ -75,7 +75,10 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W,
                                                       const __bf16* __restrict__ bias,
                                                       const __bf16* __restrict__ res, __bf16* __restrict__ out,
-                                                      int M, int N, int K, int n_tiles_n, int n_tiles) {
+                                                      int M, int N, int K, int n_tiles_n, int n_tiles,
+                                                      int group) {
+  // EPI_PATCH: row m = (image b, token t) with b = m / group; the result goes to row m + b + 1 of `out`
+  // (one class-token row per image is skipped) and `res` is the position embedding, indexed by 1 + t.
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2][kStage];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,7 +176,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
     for (int b = 0; b < 4; ++b) {
       const int m = m0 + wm * 64 + b * 16 + fr;
       if (m < M) {
-        const size_t o = (size_t)m * N + n;
+        size_t o = (size_t)m * N + n;
+        size_t ro = o;
+        if (EPI == EPI_PATCH) {
+          const int b_img = m / group;
+          o = (size_t)(m + b_img + 1) * N + n;
+          ro = (size_t)(m - b_img * group + 1) * N + n;
+        }
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] + (float)bv[j];
@@ -181,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
         }
-        if (EPI == EPI_RESIDUAL) {
-          const v4bf rv = *(const v4bf*)(res + o);
+        if (EPI == EPI_RESIDUAL || EPI == EPI_PATCH) {
+          const v4bf rv = *(const v4bf*)(res + ro);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
         }
@@ -610,13 +619,13 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
   __bf16* po = (__bf16*)out;
   switch (epilogue) {
     case EPI_BIAS:
-      hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+      hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 1);
       break;
     case EPI_GELU:
-      hipLaunchKernelGGL(gemm_kernel<EPI_GELU>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+      hipLaunchKernelGGL(gemm_kernel<EPI_GELU>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 1);
       break;
     default:
-      hipLaunchKernelGGL(gemm_kernel<EPI_RESIDUAL>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+      hipLaunchKernelGGL(gemm_kernel<EPI_RESIDUAL>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 1);
       break;
   }
   return vc::check_launch();
@@ -667,6 +676,24 @@ int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias
   else if (epilogue == EPI_GELU) { if (ln) VC_XS_LAUNCH(EPI_GELU, true); else VC_XS_LAUNCH(EPI_GELU, false); }
   else { if (ln) VC_XS_LAUNCH(EPI_RESIDUAL, true); else VC_XS_LAUNCH(EPI_RESIDUAL, false); }
 #undef VC_XS_LAUNCH
+  return vc::check_launch();
+}
+
+
+int vc_patch_embed_bf16(const void* patches, const void* weight, const void* bias, const void* pos_embed, void* out,
+                        int n_images, int tokens, int n_out, int k_in, vc_stream_t stream) {
+  if (!patches || !weight || !bias || !pos_embed || !out || n_images < 0 || tokens <= 0 || n_out <= 0 || k_in <= 0)
+    return VC_ERR_INVALID_ARG;
+  if (n_out % BN != 0 || k_in % BK != 0) return VC_ERR_UNSUPPORTED;
+  if ((((uintptr_t)patches) | ((uintptr_t)weight) | ((uintptr_t)bias) | ((uintptr_t)pos_embed) | ((uintptr_t)out)) % 16 != 0)
+    return VC_ERR_INVALID_ARG;
+  if (n_images == 0) return VC_OK;
+  const long long rows = (long long)n_images * tokens;
+  const long long nt = ((rows + BM - 1) / BM) * (n_out / BN);
+  if (rows > 0x7fffffffLL || nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gemm_kernel<EPI_PATCH>, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, (const __bf16*)patches,
+                     (const __bf16*)weight, (const __bf16*)bias, (const __bf16*)pos_embed, (__bf16*)out, (int)rows, n_out,
+                     k_in, n_out / BN, (int)nt, tokens);
   return vc::check_launch();
 }
 

@@ -32,8 +32,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned int u32;
 
-constexpr int kWaves = 8;                    // waves per workgroup (2 per SIMD)
-constexpr int kThreads = kWaves * 64;        // 512
+#ifndef VC_WAVES
+#define VC_WAVES 8
+#endif
+constexpr int kWaves = VC_WAVES;             // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+constexpr int kThreads = kWaves * 64;
 constexpr int kTile = 32;                    // MFMA tile edge
 static_assert(VC_MAX_KEYPOINTS <= 64 * 32, "the row search packs the column-tile number into 6 bits");
 constexpr int kFragBytes = 1024;             // 64 lanes x 16 B
@@ -159,6 +162,13 @@ __host__ __device__ inline size_t lds_fixed_bytes(int n_pad) {
 }
 // number of ring slots for this problem size (0 = does not fit)
 inline int plan_slots(int ks, int n_pad) {
+  if (kWaves == 4) {
+    // four-wave workgroups: stay within half the LDS when that still leaves a useful ring, so that two
+    // workgroups (two image pairs) share a CU and one's prologue / finalisation runs under the other's tiles
+    const long half = (long)kLdsBytes / 2 - (long)lds_fixed_bytes(n_pad);
+    const long nh = half / ((long)ks * kFragBytes);
+    if (nh >= 3) return (int)(nh > kMaxSlots ? kMaxSlots : nh);
+  }
   const long avail = (long)kLdsBytes - (long)lds_fixed_bytes(n_pad);
   long ns = avail / ((long)ks * kFragBytes);
   if (ns > kMaxSlots) ns = kMaxSlots;
@@ -214,7 +224,7 @@ __device__ __forceinline__ u32 lds_addr(const void* p) {
 // which makes "my pieces of tile t have landed" a counted wait: vmcnt(M * tiles issued after t).
 template <int KS>
 struct Producer {
-  static constexpr int M = KS <= 8 ? 1 : (KS + 7) / 8;
+  static constexpr int M = (KS + kWaves - 1) / kWaves;
   static constexpr int NP = KS / M;
   static_assert(NP * M == KS && NP <= kWaves, "pieces must divide evenly over the producer waves");
 };
@@ -428,6 +438,110 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// In-wave pipelining (RT = 2).  tools/overlap_probe.hip: a SIMD has ONE vector issue port — an MFMA takes it
+// for 8 of its 32 cycles, an ordinary VALU instruction for 4 — and the matrix pipe runs behind it.  Work
+// that alternates MFMA and VALU inside one wave costs max(32 N_mfma, 8 N_mfma + 4 N_valu); an MFMA cluster
+// in one wave beside a VALU cluster in its SIMD partner (the staggered halves this kernel used before) costs
+// close to the SUM, because back-to-back MFMAs keep the port.  So each wave interleaves: while the 12 MFMAs
+// of row tile 0 of column tile t issue, the relevance pass of row tile 1 of column tile t-1 runs in the
+// gaps (and vice versa for the second half); the two accumulator tiles ping-pong, no extra registers.
+// ---------------------------------------------------------------------------------------
+struct RelevancePass {   // pass 1 of the epilogue for one 32x32 tile, cut into steps
+  v4i cr[4];
+  int m;
+};
+// step 0: first row-term reads; steps 1..4: similarities of registers 4q..4q+3 and their running maximum
+// (each step reads the row terms of the next one: two of the four vectors are live)
+template <int KS>
+__device__ __forceinline__ void relevance_steps(int slot_i, const v16i& a, const int* rterm_rt, int h, int ct,
+                                                RelevancePass& st) {
+#pragma unroll
+  for (int sidx = 0; sidx < 5; ++sidx) {
+    if ((sidx * KS) / 5 != slot_i) continue;
+    if (sidx == 0) {
+      st.m = -1;
+      st.cr[0] = *(const v4i*)(rterm_rt + 4 * h);
+    } else {
+      const int q = sidx - 1;
+      if (q + 1 < 4) st.cr[q + 1] = *(const v4i*)(rterm_rt + 8 * (q + 1) + 4 * h);
+      const int v0 = a[4 * q + 0] + st.cr[q][0] + ct, v1 = a[4 * q + 1] + st.cr[q][1] + ct;
+      const int v2 = a[4 * q + 2] + st.cr[q][2] + ct, v3 = a[4 * q + 3] + st.cr[q][3] + ct;
+      st.m = max(max(st.m, max(v0, v1)), max(v2, v3));
+    }
+  }
+}
+
+// KS MFMAs of one row tile against the column tile at `src`.  The first RD B fragments arrive in `bf_io`
+// (read by the caller or by the previous half), the rest are read RD steps ahead; with NEXT the last RD
+// steps read the first fragments again for the half that follows on the same column tile, so only the
+// first half of a tile exposes the LDS latency.  `slice(i)` is issued after the i-th MFMA (sched_barrier
+// pins the interleave; the compiler places the counted waits).
+constexpr int kRd = 2;
+template <int KS, bool NEXT, typename Slice>
+__device__ __forceinline__ void mfma_half(const v4i (&af)[KS], v16i& acc, const uint8_t* src,
+                                          v4i (&bf_io)[kRd], Slice slice) {
+  constexpr int RD = KS < kRd ? KS : kRd;
+  v4i bf[KS];
+#pragma unroll
+  for (int i = 0; i < RD; ++i) bf[i] = bf_io[i];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    if (i == 0) {
+      const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0], zero, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[i], acc, 0, 0, 0);
+    }
+    if (i + RD < KS) bf[i + RD] = *(const v4i*)(src + (i + RD) * kFragBytes);
+    else if (NEXT) bf_io[i + RD - KS] = *(const v4i*)(src + (i + RD - KS) * kFragBytes);
+    slice(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// pass 2 of the epilogue for one row tile (see epilogue_phase): top-2 updates of the 16 rows a lane holds,
+// the lane's column candidates merged into LDS.  Returns whether the tile held a relevant similarity.
+template <bool FUSED>
+__device__ __forceinline__ bool update_tile(const v16i& a, u32 (&rbest)[16], u32 (&rsec)[16], const int* rterm_rt,
+                                            int ct, int jt, int rt, int c, int h, u32 row_base, int s_low,
+                                            unsigned long long* colbest, u32* colsecond) {
+  const int* rterm2 = rterm_rt;
+  asm volatile("" : "+v"(rterm2));
+  const u32 jcode = 63u - (u32)jt;
+  u32 cb = 0, cs2 = 0;
+  int m = -1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const v4i cr = *(const v4i*)(rterm2 + 8 * q + 4 * h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * q + i;
+      const int v = a[r] + cr[i] + ct;
+      m = max(m, v);
+      const u32 rk = ((u32)v << 6) | jcode;
+      rsec[r] = umed3(rbest[r], rsec[r], rk);
+      rbest[r] = umax(rbest[r], rk);
+      if (FUSED) {
+        const u32 ck = ((u32)v << 6) | (u32)(63 - (rt * kTile + (r & 3) + 8 * (r >> 2)));
+        cs2 = umed3(cb, cs2, ck);
+        cb = umax(cb, ck);
+      }
+    }
+  }
+  if (FUSED && cb != 0) {
+    const int j = jt * kTile + c;
+    const u32 sb = cb >> 6;
+    const u32 grow = row_base + (63u - (cb & 63u)) + 4u * h;
+    const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
+    const unsigned long long old = atomicMax(&colbest[j], key);
+    u32 cand = key > old ? (u32)(old >> 32) : sb;
+    cand = umax(cand, cs2 >> 6);
+    atomicMax(&colsecond[j], cand);
+  }
+  return __any(m > s_low);
+}
+
 template <int KS, int RT, bool FUSED>
 __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
@@ -486,7 +600,12 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   const int n_ct = ceil_div(n2, kTile);  // column tiles of b that hold valid rows
   const int n_pass = ceil_div(n1, kRowsPerPass);
   const int total = n_pass * n_ct;       // tiles consumed, in order (pass, jt)
+#ifdef VC_INWAVE_LOOP
+  // RT = 2 consumes two tiles per barrier, so a refill may only target the two slots of the previous iteration
+  const int pf = RT == 2 ? ns - 2 : ns - 1;
+#else
   const int pf = ns - 1;
+#endif
 
   if (total == 0) {  // an empty image: nothing can match (uniform exit)
     if (FUSED) { if (tid == 0) out_counts[p] = 0; }
@@ -518,7 +637,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   // tile t, waves 4-7 run the VALU epilogue of tile t-1, and vice versa, so the matrix pipe and the
   // vector pipe of a SIMD work at the same time instead of being fought over in lockstep.
 #ifndef VC_NO_STAGGER
-  const bool late = wave >= kWaves / 2;
+  // (with four-wave workgroups the SIMD partner is a wave of the other workgroup on the CU: no stagger)
+  const bool late = kWaves == 8 && wave >= kWaves / 2;
 #else
   constexpr bool late = false;
 #endif
@@ -572,6 +692,82 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
       }
     };
 
+#ifdef VC_INWAVE_LOOP
+    if constexpr (RT == 2) {
+      // ---- in-wave pipelined loop: see the comment above RelevancePass ----------------------------------
+      int ct_prev = 0;
+#ifdef VC_EXP_STAMP
+      unsigned long long sw = 0, sm = 0, se = 0;
+      const unsigned long long t_begin = stamp();
+      unsigned long long tp = t_begin;
+#define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - tp; tp = t_; }
+#else
+#define VC_ST(acc_)
+#endif
+      // one column tile: both halves, and the refill of one ring slot
+      auto process_tile = [&](int jt, const uint8_t* slot) {
+        const int ct = cterm[jt * kTile + c];
+        const uint8_t* src = slot + lane * 16;
+        RelevancePass p1;
+        v4i bf_io[kRd];
+#pragma unroll
+        for (int i = 0; i < (KS < kRd ? KS : kRd); ++i) bf_io[i] = *(const v4i*)(src + i * kFragBytes);
+        __builtin_amdgcn_sched_barrier(0);
+        // first half: row tile 0 of column tile jt  ||  relevance pass of row tile 1 of column tile jt-1
+        // (jt = 0: the accumulators are the zeros written above; an unreachable threshold neutralises it)
+        mfma_half<KS, true>(afrag[0], acc[0], src, bf_io, [&](int i) {
+          if (i == (KS > 1 ? 1 : 0)) produce();
+          relevance_steps<KS>(i, acc[1], crow6_wave + kTile, h, ct_prev, p1);
+        });
+        VC_ST(sm)
+        if (dense[1] || __any(p1.m > (jt > 0 ? s_low : 0x7fffffff)))
+          dense[1] = update_tile<FUSED>(acc[1], rbest[1], rsec[1], crow6_wave + kTile, ct_prev, jt - 1, 1, c, h,
+                                        row_base, s_low, colbest, colsecond);
+        VC_ST(se)
+        // second half: row tile 1 of column tile jt  ||  relevance pass of row tile 0 of column tile jt
+        mfma_half<KS, false>(afrag[1], acc[1], src, bf_io, [&](int i) { relevance_steps<KS>(i, acc[0], crow6_wave, h, ct, p1); });
+        VC_ST(sm)
+        if (dense[0] || __any(p1.m > s_low))
+          dense[0] = update_tile<FUSED>(acc[0], rbest[0], rsec[0], crow6_wave, ct, jt, 0, c, h, row_base, s_low,
+                                        colbest, colsecond);
+        VC_ST(se)
+        ct_prev = ct;
+      };
+      // Two column tiles per workgroup barrier: the waves of a SIMD drift apart by hundreds of cycles per
+      // tile (the younger one loses issue arbitration), and every barrier turns that drift into idle time.
+      for (int jt = 0; jt < n_ct; jt += 2) {
+        const bool two = jt + 1 < n_ct;
+        // the later of the tiles consumed in this iteration must have landed
+        wait_tile<KS>(wave, prod_seq - cons_seq - (two ? 2 : 1));
+        wg_barrier();
+        const uint8_t* slot0 = ring + (size_t)cons_slot * KS * kFragBytes;
+        if (++cons_slot == ns) cons_slot = 0;
+        const uint8_t* slot1 = ring + (size_t)cons_slot * KS * kFragBytes;
+        if (two && ++cons_slot == ns) cons_slot = 0;
+        cons_seq += two ? 2 : 1;
+        VC_ST(sw)
+        process_tile(jt, slot0);
+        if (two) process_tile(jt + 1, slot1);
+      }
+#ifdef VC_EXP_STAMP
+      if (FUSED && lane == 0 && pass == 0) {
+        uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
+        dbg[0] = (uint32_t)sw; dbg[1] = (uint32_t)sm; dbg[2] = (uint32_t)se;
+        dbg[3] = (uint32_t)(tp - t_begin); dbg[4] = (uint32_t)(t_begin - t_kernel_start);
+      }
+#endif
+#undef VC_ST
+      {  // row tile 1 of the last column tile has no MFMAs to ride under
+        RelevancePass p1;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) relevance_steps<KS>(i, acc[1], crow6_wave + kTile, h, ct_prev, p1);
+        if (dense[1] || __any(p1.m > s_low))
+          dense[1] = update_tile<FUSED>(acc[1], rbest[1], rsec[1], crow6_wave + kTile, ct_prev, n_ct - 1, 1, c, h,
+                                        row_base, s_low, colbest, colsecond);
+      }
+    } else
+#endif
+    {
     // Staggered halves (late = waves 4-7): one loop, the epilogue shared, only the MFMA phase
     // placed before or after it.  The late half runs the epilogue of tile jt-1; for jt = 0 that
     // call is neutralised by an unreachable threshold (its accumulators are not defined yet).
@@ -609,6 +805,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
 #endif
     if (late)
       epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low, dense);
+    }
 #undef VC_TILE_HEAD
 
     // ---- row results of this pass ------------------------------------------------------
@@ -846,7 +1043,7 @@ int launch_pair(const void* prepared, const int32_t* counts, int n_tiles, int d,
   const int s_low = FUSED ? relevance_threshold(max_ratio, max_distance) : -1;
   const int n_pad = n_tiles * kTile;
   const int ns = plan_slots(KS, n_pad);
-  if (ns == 0) return VC_ERR_UNSUPPORTED;
+  if (ns == 0 || (RT == 2 && ns < 3)) return VC_ERR_UNSUPPORTED;
   const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes(n_pad);
   static thread_local size_t configured = 0;  // per instantiation: largest size enabled so far
   if (smem > configured) {

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int kPatch = 14;
+constexpr int kPatchPad = VC_PATCH_K_PADDED;   // 588 elements padded to a multiple of the GEMM K step
 
 struct Coef {  // one source index and its two 11-bit weights
   int s0, s1;
@@ -88,7 +89,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
       o = (((size_t)n * 3 + c) * oh + y) * ow + x;
     } else {
       const int py = y / kPatch, dy = y - py * kPatch, pxx = x / kPatch, dx = x - pxx * kPatch;
-      o = ((size_t)n * hp * wp + (size_t)py * wp + pxx) * (3 * kPatch * kPatch) + (c * kPatch + dy) * kPatch + dx;
+      const int stride = layout == VC_LAYOUT_PATCHES_PAD ? kPatchPad : 3 * kPatch * kPatch;
+      o = ((size_t)n * hp * wp + (size_t)py * wp + pxx) * stride + (c * kPatch + dy) * kPatch + dx;
+      if (layout == VC_LAYOUT_PATCHES_PAD && c == 0 && dy == 0 && dx == 0) {
+        // the patch's first pixel also clears the K padding (elements 588 .. 639)
+        OutT* pad = out + ((size_t)n * hp * wp + (size_t)py * wp + pxx) * stride + 3 * kPatch * kPatch;
+        for (int i = 0; i < kPatchPad - 3 * kPatch * kPatch; ++i) store<OutT>(pad + i, 0.0f);
+      }
     }
     store<OutT>(out + o, v);
   }
@@ -102,8 +109,8 @@ int vc_preprocess_u8(const uint8_t* images_bgr, int n_images, int h, int w, int 
                      int layout, void* out, uint8_t* resized_bgr_or_null, vc_stream_t stream) {
   if (!images_bgr || !out || n_images < 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0) return VC_ERR_INVALID_ARG;
   if (out_dtype != VC_DTYPE_F32 && out_dtype != VC_DTYPE_BF16) return VC_ERR_INVALID_ARG;
-  if (layout != VC_LAYOUT_NCHW && layout != VC_LAYOUT_PATCHES) return VC_ERR_INVALID_ARG;
-  if (layout == VC_LAYOUT_PATCHES && (out_h % kPatch != 0 || out_w % kPatch != 0)) return VC_ERR_INVALID_ARG;
+  if (layout != VC_LAYOUT_NCHW && layout != VC_LAYOUT_PATCHES && layout != VC_LAYOUT_PATCHES_PAD) return VC_ERR_INVALID_ARG;
+  if (layout != VC_LAYOUT_NCHW && (out_h % kPatch != 0 || out_w % kPatch != 0)) return VC_ERR_INVALID_ARG;
   if (n_images == 0) return VC_OK;
   const dim3 grid((out_h * out_w + 255) / 256, n_images);
   if (out_dtype == VC_DTYPE_F32)

@@ -124,6 +124,10 @@ class ViTExtractor(BaseExtractor):
         """uint8 (B, h, w, 3) on the GPU -> patch tokens (B, Hp*Wp, C), Hp, Wp."""
         B, h, w, _ = images_bgr.shape
         hp, wp = h // PATCH, w // PATCH
+        if getattr(self.model, "_hip", None):
+            # ViT-S bf16: every GEMM of the forward is hand-written (csrc/gemm.hip); no hipBLASLt, no TunableOp
+            patches = hip_preprocess.preprocess(images_bgr, out_dtype=self.dtype, layout="patches_pad")
+            return self.model.forward_patch_tokens(patches, hp, wp).contiguous(), hp, wp
         patches = hip_preprocess.preprocess(images_bgr, out_dtype=self.dtype, layout="patches")
         if self.tune_gemm:
             import torch.cuda.tunable as tunable

@@ -212,6 +212,22 @@ class DinoV2(nn.Module):
     def forward_patch_tokens(self, patches: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
         """patches (B, hp*wp, 588) -> x_norm_patchtokens (B, hp*wp, C)."""
         B = patches.shape[0]
+        if patches.shape[-1] == 640:
+            # padded patches (preprocess layout "patches_pad"): patch embedding, bias and position embedding in
+            # one hand-written GEMM (csrc/gemm.hip); ViT-S bf16 GPU path only
+            if not (patches.is_cuda and patches.dtype == torch.bfloat16 and self.register_tokens is None and not self.training):
+                raise ValueError("padded patches are only accepted by the bf16 GPU path")
+            if getattr(self, "_hip", None) is None:
+                self.prepare_hip()
+            if not self._hip:
+                raise ValueError("padded patches need prepare_hip() (ViT-S)")
+            from . import hip_ops as ops
+
+            pos = self.interpolated_pos_embed(hp, wp).to(torch.bfloat16).contiguous()
+            x = torch.empty((B, 1 + hp * wp, self.arch.dim), dtype=torch.bfloat16, device=patches.device)
+            ops.patch_embed(patches, self._pe_w, self.patch_embed.proj.bias, pos, x)
+            x[:, 0] = (self.cls_token[0, 0].float() + pos[0, 0].float()).to(torch.bfloat16)
+            return self._blocks_hip(x)[:, 1:]
         x = self.patch_embed.forward_patches(patches)
         x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.interpolated_pos_embed(hp, wp)
         if self.register_tokens is not None:
@@ -237,6 +253,10 @@ class DinoV2(nn.Module):
             return self
         if not self.pos_embed.is_cuda:
             raise RuntimeError("prepare_hip needs the model on the GPU")
+        w = self.patch_embed.proj.weight.detach().float().reshape(self.arch.dim, -1)
+        wp = torch.zeros(self.arch.dim, 640, dtype=torch.float32, device=w.device)
+        wp[:, : w.shape[1]] = w
+        self._pe_w = wp.to(torch.bfloat16).contiguous()          # conv weight as a [C][640] GEMM operand (zero padded K)
         self._hip = [dict(
             qkv=XsLinear(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, b.norm1.eps),
             proj=XsLinear(b.attn.proj.weight, b.attn.proj.bias),

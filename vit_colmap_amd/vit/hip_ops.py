@@ -93,3 +93,21 @@ class XsLinear:
                                          _lib.ptr(out), rows, self.n, self.k, epilogue, int(self.ln), self.eps,
                                          _lib.stream_ptr()), "vc_linear_xs_bf16")
         return out
+
+
+PATCH_K_PADDED = 640
+
+
+def patch_embed(patches: torch.Tensor, weight_padded: torch.Tensor, bias: torch.Tensor, pos_embed: torch.Tensor,
+                out: torch.Tensor) -> torch.Tensor:
+    """out[b, 1 + t] = patches[b, t] W^T + bias + pos_embed[1 + t] (csrc/gemm.hip, EPI_PATCH); row 0 of every
+    image (class token) is left to the caller.  patches (B, T, 640) bf16 zero padded, weight (C, 640)."""
+    B, T, K = patches.shape
+    C = weight_padded.shape[0]
+    assert patches.is_cuda and patches.dtype == torch.bfloat16 and patches.is_contiguous() and K == weight_padded.shape[1]
+    assert weight_padded.is_contiguous() and bias.is_contiguous() and pos_embed.is_contiguous() and out.is_contiguous()
+    assert pos_embed.shape[-2:] == (T + 1, C) and out.shape == (B, T + 1, C) and out.dtype == torch.bfloat16
+    lib = _lib.load()
+    _lib.check(lib.vc_patch_embed_bf16(_lib.ptr(patches), _lib.ptr(weight_padded), _lib.ptr(bias), _lib.ptr(pos_embed),
+                                       _lib.ptr(out), B, T, C, K, _lib.stream_ptr()), "vc_patch_embed_bf16")
+    return out
