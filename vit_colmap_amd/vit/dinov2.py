@@ -1,4 +1,5 @@
-"""DINOv2 ViT patch-token forward for PyTorch-ROCm (bf16 on MFMA via hipBLASLt / SDPA).
+"""DINOv2 ViT patch-token forward: the module definition (hub parameter names), the weight handling and the
+bf16 GPU paths over the hand-written kernels of csrc/ (gemm.hip, attention.hip, vit_ops.hip).
 
 The reference obtains this network with `torch.hub.load("facebookresearch/dinov2", name)`
 (vit_colmap/features/vit_extractor.py:86-104) and reads `x_norm_patchtokens` from
@@ -8,13 +9,17 @@ and `forward_patch_tokens` returns the same quantity: post-final-LayerNorm patch
 (B, Hp*Wp, C), token index = y*Wp + x.
 
 MI355X-first choices
-  * the image is consumed already patchified, (B, Hp*Wp, 3*14*14): the HIP preprocessing kernel
-    (csrc/preprocess.hip) writes that layout directly, so the patch embedding is ONE GEMM instead
-    of a strided 14x14 convolution;
-  * qkv / proj / MLP are plain bf16 GEMMs over B*N rows (hipBLASLt picks the MFMA kernels), the
-    attention is `scaled_dot_product_attention` on (B, heads, N, 64);
-  * LayerScale is folded into the projection weights at load time (one multiply per element less);
-  * the whole forward is shape-static per batch size, so the extractor captures it in a hipGraph.
+  * the image is consumed already patchified, (B, Hp*Wp, 3*14*14) or zero padded to 640: the HIP preprocessing
+    kernel (csrc/preprocess.hip) writes that layout directly, so the patch embedding is ONE GEMM instead of a
+    strided 14x14 convolution;
+  * ViT-S (`_blocks_hip`): patch + position embedding, LN1+qkv, proj+residual, LN2+fc1+GELU, fc2+residual are
+    hand-written bf16 MFMA GEMMs with fused prologues / epilogues, the attention a hand-written flash kernel —
+    five kernels per block, no library GEMM and no standalone elementwise pass;
+  * other widths (`_blocks_fused`): `F.linear` (hipBLASLt) + the fused add+LayerNorm and attention kernels;
+    plain `nn.Module` path (`Block.forward`, SDPA) on the CPU / in float32 — the oracle-side evaluation;
+  * LayerScale is folded into the projection weights at load time, LayerNorm gamma / beta into the GEMM that
+    follows (`prepare_hip`);
+  * the forward is shape-static per batch size (no data-dependent control flow on the host).
 
 Architecture facts [recalled from the DINOv2 repository; pinned by tests/test_vit.py against the
 `transformers` Dinov2 implementation that ships in this image]: pre-norm blocks
