@@ -376,9 +376,10 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   // hardware, so every epilogue issues exactly two store instructions (the vmcnt bookkeeping below counts them).
   //
   // The epilogue of block i-1 is cut into 24 slices that are issued BETWEEN the 24 MFMAs of block i, in the
-  // same wave: back-to-back MFMAs of one wave hold the SIMD's vector issue port while they wait for the
-  // matrix pipe, so a partner wave's VALU-only epilogue makes no progress beside them (measured: the two
-  // waves of a SIMD ran serialised); an instruction stream that alternates MFMA and VALU shares the port.
+  // same wave (all 8 waves run the same stream, no wave roles).  tools/overlap_probe.hip: float32 VALU work does
+  // not overlap with the matrix pipe on this part however it is arranged (integer VALU work does), so this
+  // costs the same as running the epilogue as a cluster — time = MFMA time + float VALU time — and is kept
+  // for its simplicity; the lever for this kernel is fewer float instructions per output.
   const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)M * N * 2), 0x00020000);
   uint8_t* const tr_out = lds + XOffStage + wave * (2 * XChunk);
   uint8_t* const tr_res = tr_out + 2048;
@@ -528,7 +529,10 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
     {
       // W fragments are read XRD k-steps ahead of the MFMA that consumes them (LDS latency ~ 4 MFMAs);
       // sched_barrier pins [MFMA, fragment read, epilogue slice] per k-step, the compiler places the waits
-      constexpr int XRD = 8;
+#ifndef VC_XS_RD
+#define VC_XS_RD 8
+#endif
+      constexpr int XRD = VC_XS_RD;
       v8bf wf[XKS];
 #pragma unroll
       for (int ks = 0; ks < XRD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
