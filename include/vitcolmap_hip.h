@@ -231,7 +231,17 @@ int vc_linear_xs_prepare(const float* weight, const float* bias_or_null, const f
                          float* bias_folded, vc_stream_t stream);
 int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias_folded,
                       const void* residual_or_null, void* out, int rows, int n_out, int k_in, int epilogue,
-                      int fuse_layernorm, float ln_eps, vc_stream_t stream);
+                      int fuse_layernorm, float ln_eps, const void* gelu_table_or_null, vc_stream_t stream);
+/*
+ * GELU table for VC_EPI_GELU (optional): with a table the epilogue evaluates the GELU as the standard bf16
+ * pipeline does — on the bf16-ROUNDED pre-activation, result rounded to bf16, bit for bit
+ * bf16(0.5 x (1 + erff(x / sqrt 2))) — by an LDS lookup (integer work, which overlaps with the matrix pipe on
+ * gfx950 where float VALU work does not) instead of ~150 float instructions per 32x32 block.  Without a table
+ * (NULL) the GELU is evaluated in float32 on the unrounded pre-activation.  vc_gelu_table_bytes() bytes,
+ * 16-byte aligned, filled once by vc_gelu_table_bf16; used when n_out * 4 + table <= 16 KiB.
+ */
+size_t vc_gelu_table_bytes(void);
+int vc_gelu_table_bf16(void* table, vc_stream_t stream);
 
 /*
  * DINOv2 patch embedding + position embedding in one GEMM (the conv 14x14 / 14 of the hub model as a

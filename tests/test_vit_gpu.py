@@ -187,3 +187,39 @@ def test_patch_embed_gemm_matches_reference_and_padded_preprocess():
     ref = p1.float() @ w.float().t() + b.float() + pos[0, 1:].float()
     err = (out[:, 1:].float() - ref).abs()
     assert bool((err <= ref.abs() * 2 ** -8 + 1e-2).all()), float(err.max())
+
+
+def test_xs_gelu_table_is_the_bf16_gelu_for_every_input():
+    """With a table, the fc1 epilogue evaluates gelu on the bf16-rounded pre-activation and rounds to bf16.  Identity GEMM:
+    (A) every bf16 value the table covers (2^-14 <= |x| < 8) must come out as torch's bf16 gelu (float32 erf, RNE);
+    (B) every finite bf16 value at all (blocks holding an out-of-range value take the float path) within float tolerance."""
+    from vit_colmap_amd.vit.hip_ops import XsLinear, gelu_table, EPI_GELU
+
+    K = N = 384
+    lin = XsLinear(torch.eye(K, device="cuda"), torch.zeros(N, device="cuda"))
+    tab = gelu_table("cuda")
+    bits = torch.arange(0, 65536, dtype=torch.int32, device="cuda")
+    allv = bits.to(torch.int16).view(torch.bfloat16)
+    mag = allv.float().abs()
+
+    def run(vals, table):
+        rows = (vals.numel() + K - 1) // K
+        x = vals.repeat((rows * K + vals.numel() - 1) // vals.numel())[: rows * K].reshape(rows, K).contiguous()
+        out = lin(x, EPI_GELU, gelu_table=table)
+        return x.reshape(-1), out.reshape(-1)
+
+    # (A) table range only: bit pattern equality up to torch-vs-device erff last-bit differences
+    inr = allv[(mag >= 2.0 ** -14) & (mag < 8.0)]
+    assert inr.numel() == 2 * 17 * 128
+    x, out = run(inr, tab)
+    ref = torch.nn.functional.gelu(x.float()).to(torch.bfloat16)
+    d = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    assert int(d.max()) <= 1, int(d.max())
+    assert float((d != 0).float().mean()) < 2e-3, float((d != 0).float().mean())
+    # (B) all finite values, with and without the table: float32 accuracy (the float path's erf is good to 1.5e-7 absolute)
+    fin = allv[torch.isfinite(allv.float())]
+    for table in (tab, None):
+        x, out = run(fin, table)
+        ref32 = torch.nn.functional.gelu(x.float())
+        err = (out.float() - ref32).abs()
+        assert bool((err <= ref32.abs() * 2 ** -8 + 2e-7 * (1 + x.float().abs())).all()), float(err.max())

@@ -4,7 +4,7 @@ import os, sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vit_colmap_amd.vit.hip_ops import linear, XsLinear
+from vit_colmap_amd.vit.hip_ops import linear, XsLinear, gelu_table
 
 def timeit(fn, iters=30):
     for _ in range(5): fn()
@@ -29,6 +29,10 @@ for name, (K, N, epi) in {"qkv": (384, 1152, 0), "proj": (384, 384, 2), "fc1": (
             o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             tx = timeit(lambda: xs(a, epi, r, out=o))
             print(f"{name:5s} xs ln={int(ln)}: {tx*1e3:7.1f} us {fl/tx/1e9:6.0f} TF/s", flush=True)
+            if epi == 1:
+                tab = gelu_table("cuda")
+                tx = timeit(lambda: xs(a, epi, r, out=o, gelu_table=tab))
+                print(f"{name:5s} xs ln={int(ln)} GELU table: {tx*1e3:7.1f} us {fl/tx/1e9:6.0f} TF/s", flush=True)
         continue
     t_ref = timeit(lambda: F.linear(a, w, b))
     if epi == 1:

@@ -246,10 +246,37 @@ constexpr int XLds = XOffStage + 8 * 2 * XChunk;   // 72 + 16 + 64 = 152 KiB
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-template <int EPI, bool LN>
+// GELU by table (EPI_GELU with a table pointer).  float32 VALU work does not overlap with the matrix pipe on
+// this part, integer VALU work and LDS reads do (tools/overlap_probe.hip), and the exact GELU is ~150 float
+// instructions per block and wave.  The standard bf16 pipeline evaluates gelu on the bf16-ROUNDED pre-activation
+// and rounds the result to bf16, i.e. it is a function from 16 bits to 16 bits: for 2^-14 <= |x| < 8 it is looked
+// up in LDS (17 exponents x 128 mantissas x 2 signs = 4352 entries of 2 bytes, entry [k][sign] with
+// k = (bits & 0x7fff) - kGtLo), the index arithmetic is integer work.  A wave that holds a value outside that
+// range (|x| >= 8, |x| < 2^-14, NaN) takes the float path for the block (rare).  Table values: 0.5 x (1 + erff(x / sqrt 2))
+// in float32, rounded to nearest-even — what torch's bf16 gelu computes.
+constexpr uint32_t kGtLo = (127 - 14) << 7;                 // bf16 bits of 2^-14
+constexpr uint32_t kGtN = 17 * 128;                         // magnitudes covered: [2^-14, 8)
+constexpr int kGtBytes = (int)kGtN * 2 * 2;                 // 8704
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__global__ void gelu_table_kernel(uint16_t* __restrict__ tab) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kGtN * 2) return;
+  const uint32_t k = i >> 1, sign = i & 1;
+  const float x = __uint_as_float(((sign << 15) | (kGtLo + k)) << 16);
+  const float y = 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  tab[i] = (uint16_t)f32_to_bf16_rne(y);
+}
+
+template <int EPI, bool LN, bool GT>
 __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X, const uint8_t* __restrict__ Wp,
                                                     const float* __restrict__ biasf, const __bf16* res,
-                                                    __bf16* out, int M, int N, int n_nb, int n_stages, float eps) {
+                                                    __bf16* out, int M, int N, int n_nb, int n_stages, float eps,
+                                                    const uint16_t* __restrict__ gelu_tab) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[XLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,6 +289,10 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
 
   float* bias_l = (float*)(lds + XOffBias);
   for (int i = tid; i < N; i += 512) bias_l[i] = biasf[i];   // visible after the first stage barrier
+  // GELU table behind the bias (the host checks that both fit the 16 KiB area)
+  uint8_t* const gt_l = lds + XOffBias + ((N * 4 + 15) & ~15);
+  if (GT)
+    for (int i = tid; i < kGtBytes / 4; i += 512) ((uint32_t*)gt_l)[i] = ((const uint32_t*)gelu_tab)[i];
 
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0]);
   // ---- producer: wave w issues pieces 3w..3w+2 of every stage ------------------------------------
@@ -408,11 +439,81 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
       }
     }
   };
+  uint32_t gq[8];        // table GELU: looked-up halves in flight (ring of 4 packed registers)
+  uint32_t gres[8];      // ... results, packed bf16 pairs, parked until the range check
+  uint32_t gbad = 0;     // ... largest table index seen (out-of-range detector)
   auto slice = [&](int sl) {
 #ifdef VC_XS_NOEPI
     if (sl == 23 && pa[0] == 12345.678f && pa[7] == 1.25f) out[pnb] = (__bf16)pa[1];
     return;
 #endif
+    if (EPI == EPI_GELU && GT) {
+      // slices 0-3: pre-activations -> bf16 pairs (ep), the only float work; 4-11: table index + LDS gather of
+      // packed register sl-4; 7-14: results packed back; 15: range check (+ float path); 16/17/19/22: exchange,
+      // transposer write / read, store
+      typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+      if (sl < 4) {
+        const int g = sl;
+        const v2bf lo = {(__bf16)pa[4 * g], (__bf16)pa[4 * g + 1]}, hi = {(__bf16)pa[4 * g + 2], (__bf16)pa[4 * g + 3]};
+        ep[2 * g] = *(const uint32_t*)&lo;
+        ep[2 * g + 1] = *(const uint32_t*)&hi;
+        if (sl == 0) gbad = 0;
+      }
+      if (sl >= 4 && sl < 12) {
+        const int qd = sl - 4;
+        const uint32_t b0 = ep[qd] & 0xffffu, b1 = ep[qd] >> 16;
+        const uint32_t k0 = (b0 & 0x7fffu) - kGtLo, k1 = (b1 & 0x7fffu) - kGtLo;   // wraps to a huge value below the range
+        gbad = max(gbad, max(k0, k1));
+        const uint32_t a0 = min(k0, kGtN - 1) * 4 + ((b0 >> 15) << 1), a1 = min(k1, kGtN - 1) * 4 + ((b1 >> 15) << 1);
+        gq[2 * (qd & 3)] = *(const uint16_t*)(gt_l + a0);
+        gq[2 * (qd & 3) + 1] = *(const uint16_t*)(gt_l + a1);
+      }
+      if (sl >= 7 && sl < 15) {        // three slices (~100+ cycles) after the gather was issued
+        const int qd = sl - 7;
+        gres[qd] = gq[2 * (qd & 3)] | (gq[2 * (qd & 3) + 1] << 16);
+      }
+      if (sl == 15) {
+        if (__any(gbad >= kGtN)) {       // a value outside the table's range somewhere in the wave: float path for the block
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd) {
+            const v2f_t xin = {__uint_as_float(ep[qd] << 16), __uint_as_float(ep[qd] & 0xffff0000u)};
+            const v2f_t y = gelu_erf2(xin);
+            const v2bf o = {(__bf16)y[0], (__bf16)y[1]};
+            ep[qd] = *(const uint32_t*)&o;
+          }
+        } else {
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd) ep[qd] = gres[qd];
+        }
+      }
+      if (sl == 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(ep[i], ep[i + 4], false, false);
+          ep[i] = sw[0];
+          ep[i + 4] = sw[1];
+        }
+      }
+      if (sl == 17) {
+        *(v4u*)(tr_out + r * 64 + (((2 * h) ^ rsw) << 4)) = (v4u){ep[0], ep[1], ep[4], ep[5]};
+        *(v4u*)(tr_out + r * 64 + (((2 * h + 1) ^ rsw) << 4)) = (v4u){ep[2], ep[3], ep[6], ep[7]};
+      }
+      if (sl == 19) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = crow + 16 * q;
+          eo[q] = *(const v4u*)(tr_out + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4));
+        }
+      }
+      if (sl == 22) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = crow + 16 * q;
+          __builtin_amdgcn_raw_buffer_store_b128(eo[q], out_rs, (int)(((size_t)(pm_base + row) * N + pnb * 32 + cch * 8) * 2), 0, 0);
+        }
+      }
+      return;
+    }
     if (sl < 8) {                       // values 2 sl, 2 sl + 1
       const int j0 = 2 * sl;
       if (EPI == EPI_GELU) {
@@ -532,7 +633,7 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
 #ifndef VC_XS_RD
 #define VC_XS_RD 8
 #endif
-      constexpr int XRD = VC_XS_RD;
+      constexpr int XRD = (EPI == EPI_GELU && GT) ? 6 : VC_XS_RD;   // the table epilogue needs the registers
       v8bf wf[XKS];
 #pragma unroll
       for (int ks = 0; ks < XRD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
@@ -652,9 +753,17 @@ int vc_linear_xs_prepare(const float* weight, const float* bias_or_null, const f
   return vc::check_launch();
 }
 
+size_t vc_gelu_table_bytes(void) { return (size_t)kGtBytes; }
+
+int vc_gelu_table_bf16(void* table, vc_stream_t stream) {
+  if (!table || ((uintptr_t)table) % 16 != 0) return VC_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gelu_table_kernel, dim3((kGtN * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint16_t*)table);
+  return vc::check_launch();
+}
+
 int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias_folded, const void* residual_or_null,
                       void* out, int rows, int n_out, int k_in, int epilogue, int fuse_layernorm, float ln_eps,
-                      vc_stream_t stream) {
+                      const void* gelu_table_or_null, vc_stream_t stream) {
   if (!x || !weight_tiled || !bias_folded || !out || rows < 0 || n_out <= 0) return VC_ERR_INVALID_ARG;
   if (epilogue < EPI_BIAS || epilogue > EPI_RESIDUAL) return VC_ERR_INVALID_ARG;
   if ((epilogue == EPI_RESIDUAL) != (residual_or_null != nullptr)) return VC_ERR_INVALID_ARG;
@@ -673,12 +782,19 @@ int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias
   const __bf16 *px = (const __bf16*)x, *pr = (const __bf16*)residual_or_null;
   const uint8_t* pw = (const uint8_t*)weight_tiled;
   __bf16* po = (__bf16*)out;
-#define VC_XS_LAUNCH(E, L) \
-  hipLaunchKernelGGL((xs_kernel<E, L>), grid, block, 0, s, px, pw, bias_folded, pr, po, rows, n_out, n_nb, (int)stages, ln_eps)
+  const uint16_t* gt = (const uint16_t*)gelu_table_or_null;
+  if (gt && (((uintptr_t)gt) % 16 != 0)) return VC_ERR_INVALID_ARG;
+  // the table shares the 16 KiB staging area with the bias
+  const bool use_gt = gt && epilogue == EPI_GELU && ((n_out * 4 + 15) & ~15) + kGtBytes <= XMaxN * 4;
+#define VC_XS_LAUNCH(E, L, G) \
+  hipLaunchKernelGGL((xs_kernel<E, L, G>), grid, block, 0, s, px, pw, bias_folded, pr, po, rows, n_out, n_nb, (int)stages, ln_eps, gt)
   const bool ln = fuse_layernorm != 0;
-  if (epilogue == EPI_BIAS) { if (ln) VC_XS_LAUNCH(EPI_BIAS, true); else VC_XS_LAUNCH(EPI_BIAS, false); }
-  else if (epilogue == EPI_GELU) { if (ln) VC_XS_LAUNCH(EPI_GELU, true); else VC_XS_LAUNCH(EPI_GELU, false); }
-  else { if (ln) VC_XS_LAUNCH(EPI_RESIDUAL, true); else VC_XS_LAUNCH(EPI_RESIDUAL, false); }
+  if (epilogue == EPI_BIAS) { if (ln) VC_XS_LAUNCH(EPI_BIAS, true, false); else VC_XS_LAUNCH(EPI_BIAS, false, false); }
+  else if (epilogue == EPI_GELU) {
+    if (use_gt) { if (ln) VC_XS_LAUNCH(EPI_GELU, true, true); else VC_XS_LAUNCH(EPI_GELU, false, true); }
+    else { if (ln) VC_XS_LAUNCH(EPI_GELU, true, false); else VC_XS_LAUNCH(EPI_GELU, false, false); }
+  }
+  else { if (ln) VC_XS_LAUNCH(EPI_RESIDUAL, true, false); else VC_XS_LAUNCH(EPI_RESIDUAL, false, false); }
 #undef VC_XS_LAUNCH
   return vc::check_launch();
 }

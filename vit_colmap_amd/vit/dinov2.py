@@ -252,6 +252,7 @@ class DinoV2(nn.Module):
         float32 (after fold_layerscale, on the GPU) so gamma is folded before the one rounding to bf16;
         `_blocks_fused` calls it lazily otherwise.  Only the 384-wide MLP models (ViT-S) are covered."""
         from .hip_ops import XsLinear
+        from .hip_ops import gelu_table as hip_ops_gelu_table
 
         self._hip = False
         if self.arch.dim != 384 or self.arch.ffn != "mlp" or not all(b.folded for b in self.blocks):
@@ -262,6 +263,7 @@ class DinoV2(nn.Module):
         wp = torch.zeros(self.arch.dim, 640, dtype=torch.float32, device=w.device)
         wp[:, : w.shape[1]] = w
         self._pe_w = wp.to(torch.bfloat16).contiguous()          # conv weight as a [C][640] GEMM operand (zero padded K)
+        self._gelu_tab = hip_ops_gelu_table(w.device)
         self._hip = [dict(
             qkv=XsLinear(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, b.norm1.eps),
             proj=XsLinear(b.attn.proj.weight, b.attn.proj.bias),
@@ -277,7 +279,7 @@ class DinoV2(nn.Module):
         for blk, hw in zip(self.blocks, self._hip):
             a = ops.attention(hw["qkv"](x), blk.attn.num_heads)           # LN1 + qkv, then flash attention
             hw["proj"](a, ops.EPI_RESIDUAL, residual=x, out=x)            # x += proj(a)
-            hdn = hw["fc1"](x, ops.EPI_GELU)                              # gelu(fc1(LN2 x))
+            hdn = hw["fc1"](x, ops.EPI_GELU, gelu_table=self._gelu_tab)   # gelu(fc1(LN2 x)), GELU by LDS table
             fc2 = blk.mlp.fc2
             ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=x, out=x)   # x += fc2(hdn)
         _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)

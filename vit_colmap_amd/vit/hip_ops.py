@@ -81,7 +81,7 @@ class XsLinear:
         _lib.check(lib.vc_linear_xs_prepare(_lib.ptr(w), _lib.ptr(b), _lib.ptr(g), _lib.ptr(be), n, k, _lib.ptr(self.wp),
                                             _lib.ptr(self.bias), _lib.stream_ptr()), "vc_linear_xs_prepare")
 
-    def __call__(self, x: torch.Tensor, epilogue: int = EPI_BIAS, residual=None, out=None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, epilogue: int = EPI_BIAS, residual=None, out=None, gelu_table=None) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == self.k
         rows = x.numel() // self.k
         if out is None:
@@ -91,7 +91,7 @@ class XsLinear:
         lib = _lib.load()
         _lib.check(lib.vc_linear_xs_bf16(_lib.ptr(x), _lib.ptr(self.wp), _lib.ptr(self.bias), _lib.ptr(residual),
                                          _lib.ptr(out), rows, self.n, self.k, epilogue, int(self.ln), self.eps,
-                                         _lib.stream_ptr()), "vc_linear_xs_bf16")
+                                         _lib.ptr(gelu_table), _lib.stream_ptr()), "vc_linear_xs_bf16")
         return out
 
 
@@ -111,3 +111,17 @@ def patch_embed(patches: torch.Tensor, weight_padded: torch.Tensor, bias: torch.
     _lib.check(lib.vc_patch_embed_bf16(_lib.ptr(patches), _lib.ptr(weight_padded), _lib.ptr(bias), _lib.ptr(pos_embed),
                                        _lib.ptr(out), B, T, C, K, _lib.stream_ptr()), "vc_patch_embed_bf16")
     return out
+
+
+_GELU_TABLES = {}
+
+
+def gelu_table(device) -> torch.Tensor:
+    """The bf16 -> bf16 GELU lookup table of csrc/gemm.hip (one per device, built on first use)."""
+    key = torch.device(device)
+    if key not in _GELU_TABLES:
+        lib = _lib.load()
+        t = torch.empty(lib.vc_gelu_table_bytes(), dtype=torch.uint8, device=key)
+        _lib.check(lib.vc_gelu_table_bf16(_lib.ptr(t), _lib.stream_ptr()), "vc_gelu_table_bf16")
+        _GELU_TABLES[key] = t
+    return _GELU_TABLES[key]
