@@ -186,9 +186,12 @@ int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const voi
  * Multi-head self-attention forward, head_dim 64 (DINOv2 ViT-S/B/L): softmax(Q K^T / 8) V.
  * qkv [batch][n_tokens][3][n_heads][64] bfloat16 (the fused qkv projection's output as it is),
  * out [batch][n_tokens][n_heads*64] bfloat16 (what the output projection reads).  16-byte aligned.
+ * q_prescaled != 0: the q part of qkv already carries the factor (1/8) * log2(e) (fold it into the rows of the qkv
+ * projection that produce q, weights and bias): the kernel then subtracts the running row maximum inside the matrix
+ * product and evaluates exp2 of the accumulator directly — one float instruction less per score, same softmax.
  */
-int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, void* out,
-                      vc_stream_t stream);
+int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, int q_prescaled,
+                      void* out, vc_stream_t stream);
 
 /*
  * Linear layer with fused epilogue (bf16 in, float32 accumulate on MFMA, bf16 out):

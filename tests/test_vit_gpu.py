@@ -223,3 +223,26 @@ def test_xs_gelu_table_is_the_bf16_gelu_for_every_input():
         ref32 = torch.nn.functional.gelu(x.float())
         err = (out.float() - ref32).abs()
         assert bool((err <= ref32.abs() * 2 ** -8 + 2e-7 * (1 + x.float().abs())).all()), float(err.max())
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 1531, 6), (1, 64, 1), (3, 257, 12), (1, 100, 2), (1, 1, 6)])
+@pytest.mark.parametrize("spread", [1.0, 6.0])
+def test_attention_prescaled_q_lazy_max(B, N, H, spread):
+    """q_prescaled mode (q carries (1/8) log2 e; running maximum subtracted inside the product, deferred max) vs float32
+    softmax on the same bf16 data.  spread 6: score ranges wide enough that later blocks exceed the running maximum by
+    more than the lazy threshold, so the exact-rescale path runs too."""
+    import math
+    from vit_colmap_amd.vit.hip_ops import attention
+
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + N + H)
+    qkv = torch.randn(B, N, 3, H, 64, device="cuda", generator=g)
+    qkv[:, :, 0] *= spread * 0.125 * math.log2(math.e)
+    # make late keys larger so that the running maximum keeps moving
+    qkv[:, :, 1] *= torch.linspace(0.5, 1.5, N, device="cuda")[None, :, None, None]
+    qkv = qkv.to(torch.bfloat16).reshape(B, N, 3 * H * 64).contiguous()
+    out = attention(qkv, H, q_prescaled=True).float()
+    q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(q @ k.transpose(-1, -2) * math.log(2.0), dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B, N, H * 64)
+    err = (out - ref).abs()
+    assert float(err.max()) < 3e-2 and float((out - ref).norm() / ref.norm()) < 1e-2, (float(err.max()), float((out - ref).norm() / ref.norm()))

@@ -50,7 +50,16 @@ __device__ inline uint32_t v_off(int key, int byte_in_row) {
 
 // QT = 32-query tiles per wave.  QT = 2 reads every K / V fragment from LDS once for two MFMAs and
 // stages every K / V tile once for 256 instead of 128 query rows (at 2 waves per SIMD instead of 3).
-template <int QT>
+// LAZY: the queries arrive already multiplied by scale * log2(e) (folded into the qkv projection), and from the
+// second key block on the running maximum is subtracted INSIDE the matrix product — it is the accumulator's
+// initial value — so a probability is exp2(accumulator) with no v_fma_f32 per score, and the per-block maximum
+// is only an integer test "some score exceeds the running maximum by more than kLazyTh" (float bit patterns of
+// positive numbers order as integers).  Any reference value gives the same softmax after normalisation; the
+// exact maximum is re-established (standard rescale) when the test fires, so probabilities stay <= 2^kLazyTh.
+// float32 VALU work does not overlap with the matrix pipe on gfx950 (tools/overlap_probe.hip): removing one of the
+// five float issue slots per score is a direct saving.
+constexpr float kLazyTh = 6.0f;
+template <int QT, bool LAZY>
 __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const __bf16* __restrict__ qkv,
                                                                            __bf16* __restrict__ out, int N, int H,
                                                                            float scale_log2e) {
@@ -136,11 +145,14 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
     // ---- S^T = K Q^T : two 32-key tiles (each K fragment feeds QT MFMAs) -----------------------
     v16f acc_s[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+    for (int qt = 0; qt < QT; ++qt) {
+      // LAZY: the running maximum of the lane's query (log2 units) is subtracted by the MFMA itself
+      const float c0 = (LAZY && blk > 0) ? -m_run[qt] : 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc_s[qt][t][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc_s[qt][t][i] = c0;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = t * 32 + r;
@@ -170,6 +182,34 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
     v8bf pf[QT][4];  // P^T as B operand: k-step s <- registers 8(s&1)..+7 of tile s>>1
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+      if (LAZY && blk > 0) {
+        // scores are relative to the running maximum already; integer test for "one of them is too large"
+        int imax = __float_as_int(acc_s[qt][0][0]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) imax = max(imax, __float_as_int(acc_s[qt][t][i]));
+        if (!__any(imax > __float_as_int(kLazyTh))) {
+          float lsum = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int t = s >> 1, r0 = 8 * (s & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float pj = __builtin_amdgcn_exp2f(acc_s[qt][t][r0 + j]);
+              lsum += pj;
+              pf[qt][s][j] = (__bf16)pj;
+            }
+          }
+          l_run[qt] += lsum;
+          continue;
+        }
+        // rare: back to absolute scores, then the standard update below
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_s[qt][t][i] += m_run[qt];
+      }
       float mloc = acc_s[qt][0][0];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -251,23 +291,25 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
 
 extern "C" {
 
-int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, void* out,
+int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int head_dim, int q_prescaled, void* out,
                       vc_stream_t stream) {
   if (!qkv || !out || batch < 0 || n_tokens <= 0 || n_heads <= 0) return VC_ERR_INVALID_ARG;
   if (head_dim != kHD) return VC_ERR_UNSUPPORTED;
   if ((((uintptr_t)qkv) | ((uintptr_t)out)) % 16 != 0) return VC_ERR_INVALID_ARG;
   if (batch == 0) return VC_OK;
-  const float scale_log2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  // q_prescaled: the q rows already carry 1/sqrt(64) * log2(e) (folded into the qkv projection)
+  const float scale_log2e = q_prescaled ? 1.0f : 0.125f * 1.4426950408889634f;
   // two query tiles per wave once the sequence is long enough to fill the chip with 256-row blocks
   int qt = n_tokens >= 512 ? 2 : 1;
   if (const char* e = getenv("VITCOLMAP_ATTN_QT")) qt = atoi(e) == 1 ? 1 : 2;   // developer A/B switch
   const dim3 grid((n_tokens + kQB * qt - 1) / (kQB * qt), batch * n_heads);
-  if (qt == 1)
-    hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv,
-                       (__bf16*)out, n_tokens, n_heads, scale_log2e);
-  else
-    hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv,
-                       (__bf16*)out, n_tokens, n_heads, scale_log2e);
+  const __bf16* pq = (const __bf16*)qkv;
+  __bf16* po = (__bf16*)out;
+  hipStream_t st = (hipStream_t)stream;
+#define VC_ATT(Q, L) hipLaunchKernelGGL((attention_kernel<Q, L>), grid, dim3(256), 0, st, pq, po, n_tokens, n_heads, scale_log2e)
+  if (qt == 1) { if (q_prescaled) VC_ATT(1, true); else VC_ATT(1, false); }
+  else { if (q_prescaled) VC_ATT(2, true); else VC_ATT(2, false); }
+#undef VC_ATT
   return vc::check_launch();
 }
 

@@ -265,7 +265,7 @@ class DinoV2(nn.Module):
         self._pe_w = wp.to(torch.bfloat16).contiguous()          # conv weight as a [C][640] GEMM operand (zero padded K)
         self._gelu_tab = hip_ops_gelu_table(w.device)
         self._hip = [dict(
-            qkv=XsLinear(b.attn.qkv.weight, b.attn.qkv.bias, b.norm1.weight, b.norm1.bias, b.norm1.eps),
+            qkv=XsLinear(*_prescale_q(b.attn.qkv.weight, b.attn.qkv.bias, self.arch.dim), b.norm1.weight, b.norm1.bias, b.norm1.eps),
             proj=XsLinear(b.attn.proj.weight, b.attn.proj.bias),
             fc1=XsLinear(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm2.weight, b.norm2.bias, b.norm2.eps),
         ) for b in self.blocks]
@@ -277,7 +277,7 @@ class DinoV2(nn.Module):
         from . import hip_ops as ops
 
         for blk, hw in zip(self.blocks, self._hip):
-            a = ops.attention(hw["qkv"](x), blk.attn.num_heads)           # LN1 + qkv, then flash attention
+            a = ops.attention(hw["qkv"](x), blk.attn.num_heads, q_prescaled=True)   # LN1 + qkv (q pre-scaled), flash attention
             hw["proj"](a, ops.EPI_RESIDUAL, residual=x, out=x)            # x += proj(a)
             hdn = hw["fc1"](x, ops.EPI_GELU, gelu_table=self._gelu_tab)   # gelu(fc1(LN2 x)), GELU by LDS table
             fc2 = blk.mlp.fc2
@@ -312,6 +312,18 @@ class DinoV2(nn.Module):
         hp, wp = H // PATCH, W // PATCH
         patches = image.reshape(B, 3, hp, PATCH, wp, PATCH).permute(0, 2, 4, 1, 3, 5).reshape(B, hp * wp, 3 * PATCH * PATCH)
         return {"x_norm_patchtokens": self.forward_patch_tokens(patches, hp, wp)}
+
+
+def _prescale_q(weight, bias, dim):
+    """qkv projection with the softmax scale and log2(e) folded into the q rows (float32, before any rounding):
+    what csrc/attention.hip's `q_prescaled` mode consumes."""
+    from .hip_ops import Q_PRESCALE
+
+    w = weight.detach().float().clone()
+    b = bias.detach().float().clone()
+    w[:dim] *= Q_PRESCALE
+    b[:dim] *= Q_PRESCALE
+    return w, b
 
 
 def build_dinov2(model_name: str = "dinov2_vitb14", interpolate_offset: float = 0.1) -> DinoV2:

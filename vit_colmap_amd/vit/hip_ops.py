@@ -20,14 +20,18 @@ def add_layernorm(x: torch.Tensor, residual, weight: torch.Tensor, bias: torch.T
     return s, y
 
 
-def attention(qkv: torch.Tensor, n_heads: int) -> torch.Tensor:
-    """qkv (B, N, 3*H*64) bf16 contiguous -> softmax(QK^T/8)V as (B, N, H*64) bf16 (csrc/attention.hip)."""
+Q_PRESCALE = 0.125 * 1.4426950408889634   # 1/sqrt(64) * log2(e): what `q_prescaled=True` expects folded into q
+
+
+def attention(qkv: torch.Tensor, n_heads: int, q_prescaled: bool = False) -> torch.Tensor:
+    """qkv (B, N, 3*H*64) bf16 contiguous -> softmax(QK^T/8)V as (B, N, H*64) bf16 (csrc/attention.hip).
+    q_prescaled: the q part already carries Q_PRESCALE (folded into the qkv projection)."""
     assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     B, N, C3 = qkv.shape
     hd = C3 // (3 * n_heads)
     lib = _lib.load()
     out = torch.empty((B, N, C3 // 3), dtype=torch.bfloat16, device=qkv.device)
-    _lib.check(lib.vc_attention_bf16(_lib.ptr(qkv), B, N, n_heads, hd, _lib.ptr(out), _lib.stream_ptr()),
+    _lib.check(lib.vc_attention_bf16(_lib.ptr(qkv), B, N, n_heads, hd, int(q_prescaled), _lib.ptr(out), _lib.stream_ptr()),
                "vc_attention_bf16")
     return out
 
