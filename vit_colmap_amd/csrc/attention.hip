@@ -190,6 +190,22 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
 #pragma unroll
           for (int i = 0; i < 16; ++i) imax = max(imax, __float_as_int(acc_s[qt][t][i]));
         if (!__any(imax > __float_as_int(kLazyTh))) {
+#ifdef VC_ATTN_PKSUM
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          v2f lsum2 = {0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int t = s >> 1, r0 = 8 * (s & 1);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const v2f pj = {__builtin_amdgcn_exp2f(acc_s[qt][t][r0 + j]), __builtin_amdgcn_exp2f(acc_s[qt][t][r0 + j + 1])};
+              lsum2 += pj;
+              pf[qt][s][j] = (__bf16)pj[0];
+              pf[qt][s][j + 1] = (__bf16)pj[1];
+            }
+          }
+          l_run[qt] += lsum2[0] + lsum2[1];
+#else
           float lsum = 0.f;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -202,6 +218,7 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
             }
           }
           l_run[qt] += lsum;
+#endif
           continue;
         }
         // rare: back to absolute scores, then the standard update below
