@@ -181,3 +181,49 @@ def test_pipeline_dispatch(tmp_path):
     image_io.imwrite(d / "a.png", checkerboard())
     assert Pipeline(c).run(d, tmp_path / "out", tmp_path / "db" / "database.db") is None
     assert (tmp_path / "out").exists() and (tmp_path / "db" / "database.db").exists()
+
+
+def test_metrics_extractor_reads_back_what_the_writer_stored(tmp_path):
+    """the reference's database metrics (utils/metrics.py:144-268) over a database written here."""
+    import json
+    import sqlite3
+
+    import numpy as np
+
+    from vit_colmap_amd.database import ColmapDatabase
+    from vit_colmap_amd.utils import MetricsExtractor
+
+    db_path = tmp_path / "m.db"
+    db = ColmapDatabase(str(db_path))
+    cam = db.add_pinhole_camera(640, 480, 640.0, 640.0, 320.0, 240.0)
+    counts = [5, 9, 2, 12]
+    ids = []
+    for i, n in enumerate(counts):
+        iid = db.add_image(f"im{i}.png", cam)
+        ids.append(iid)
+        db.add_keypoints(iid, np.zeros((n, 2), np.float32))
+        db.add_descriptors(iid, np.zeros((n, 8), np.uint8))
+    raw = {(0, 1): 4, (0, 2): 0, (1, 3): 7}
+    for (a, b), n in raw.items():
+        db.add_matches(ids[a], ids[b], np.zeros((n, 2), np.uint32))
+    db.commit()
+    mx = MetricsExtractor(db_path, tmp_path)
+    f = mx.extract_feature_metrics()
+    assert (f.total_images, f.total_keypoints, f.min_keypoints, f.max_keypoints) == (4, 28, 2, 12)
+    assert f.avg_keypoints_per_image == 7.0 and f.median_keypoints == 7.0
+    m = mx.extract_matching_metrics(min_threshold=3)
+    assert (m.total_image_pairs, m.matched_pairs, m.verified_pairs) == (6, 3, 0)
+    assert m.match_rate == 50.0 and m.total_raw_matches == 11 and (m.min_raw_matches, m.max_raw_matches) == (0, 7)
+    assert m.median_raw_matches == 4.0 and m.inlier_ratio == 0 and m.verification_rate == 0 and m.config_distribution == {}
+    # verified pairs, as COLMAP's geometric verification would add them
+    conn = sqlite3.connect(str(db_path))
+    conn.execute("INSERT INTO two_view_geometries(pair_id, rows, cols, data, config) VALUES (?, 3, 2, NULL, 2)", (1,))
+    conn.execute("INSERT INTO two_view_geometries(pair_id, rows, cols, data, config) VALUES (?, 5, 2, NULL, 3)", (2,))
+    conn.commit()
+    conn.close()
+    m = mx.extract_matching_metrics(min_threshold=4)
+    assert (m.verified_pairs, m.total_inlier_matches, m.pairs_above_threshold) == (2, 8, 1)
+    assert abs(m.inlier_ratio - 8 / 11) < 1e-12 and abs(m.verification_rate - 200 / 3) < 1e-9
+    assert m.config_distribution == {"CALIBRATED": 1, "UNCALIBRATED": 1}
+    out = mx.export_json(tmp_path / "r" / "metrics.json", min_threshold=4)
+    assert json.loads((tmp_path / "r" / "metrics.json").read_text()) == out and out["features"]["total_keypoints"] == 28
