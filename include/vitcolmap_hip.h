@@ -258,6 +258,21 @@ int vc_gelu_table_bf16(void* table, vc_stream_t stream);
 int vc_patch_embed_bf16(const void* patches, const void* weight, const void* bias, const void* pos_embed,
                         void* out, int n_images, int tokens, int n_out, int k_in, vc_stream_t stream);
 
+/*
+ * Fused MLP of a pre-norm block for dim == 384 (ViT-S):  x += fc2(gelu(fc1(LayerNorm(x))))  in one kernel — the
+ * hidden tensor never exists in memory (csrc/gemm.hip, mlp_kernel).  GELU as in vc_linear_xs_bf16 with a table.
+ * vc_mlp_prepare (once per block): w1 [n_hidden][384], b1 [n_hidden], LayerNorm gamma / beta [384] (or both NULL),
+ *   w2 [384][n_hidden], b2 [384], all float32  ->  weights_tiled (vc_mlp_weight_bytes bytes, stage order), b1_folded
+ *   [n_hidden] float32, b2_out [384] float32.  n_hidden % 32 == 0, n_hidden <= 2048.
+ * vc_mlp_bf16: x_inout [rows][384] bf16, updated in place.  gelu_table from vc_gelu_table_bf16.
+ */
+size_t vc_mlp_weight_bytes(int n_hidden, int dim);
+int vc_mlp_prepare(const float* w1, const float* b1_or_null, const float* ln_gamma_or_null,
+                   const float* ln_beta_or_null, const float* w2, const float* b2_or_null, int n_hidden, int dim,
+                   void* weights_tiled, float* b1_folded, float* b2_out, vc_stream_t stream);
+int vc_mlp_bf16(void* x_inout, const void* weights_tiled, const float* b1_folded, const float* b2,
+                const void* gelu_table, int rows, int n_hidden, int dim, float ln_eps, vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,3 +246,29 @@ def test_attention_prescaled_q_lazy_max(B, N, H, spread):
     ref = (att @ v).transpose(1, 2).reshape(B, N, H * 64)
     err = (out - ref).abs()
     assert float(err.max()) < 3e-2 and float((out - ref).norm() / ref.norm()) < 1e-2, (float(err.max()), float((out - ref).norm() / ref.norm()))
+
+
+@pytest.mark.parametrize("rows", [1, 127, 128, 300, 1531 * 3])
+def test_fused_mlp_matches_float32_reference(rows):
+    """x += fc2(gelu(fc1(LN(x)))) in one kernel vs the float32 evaluation (GELU on the bf16-rounded pre-activation, as the
+    bf16 pipeline and the kernel's table define it)."""
+    from vit_colmap_amd.vit.hip_ops import FusedMlp
+
+    K, Hd = 384, 1536
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = (torch.randn(rows, K, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w1 = torch.randn(Hd, K, device="cuda", generator=g) / K ** 0.5 * torch.linspace(0.5, 2.0, Hd, device="cuda")[:, None]
+    b1 = 0.5 * torch.randn(Hd, device="cuda", generator=g)
+    w2 = torch.randn(K, Hd, device="cuda", generator=g) / Hd ** 0.5 * torch.linspace(0.5, 1.5, K, device="cuda")[:, None]
+    b2 = torch.randn(K, device="cuda", generator=g)
+    gam = 1 + 0.2 * torch.randn(K, device="cuda", generator=g)
+    bet = 0.1 * torch.randn(K, device="cuda", generator=g)
+    mlp = FusedMlp(w1, b1, gam, bet, w2, b2, 1e-6)
+    xin = x.float()
+    h = torch.nn.functional.layer_norm(xin, (K,), gam, bet, 1e-6) @ w1.t() + b1
+    hg = torch.nn.functional.gelu(h.to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    ref = xin + hg @ w2.t() + b2
+    out = mlp(x.clone()).float()
+    err = (out - ref).abs()
+    assert float((out - ref).norm() / ref.norm()) < 8e-3, float((out - ref).norm() / ref.norm())
+    assert bool((err <= ref.abs() * 2 ** -6 + 0.12).all()), (float(err.max()), int((err > ref.abs() * 2 ** -6 + 0.12).sum()))

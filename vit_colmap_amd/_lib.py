@@ -55,6 +55,10 @@ SIGNATURES = {
     "vc_gelu_table_bytes": (c_size_t, []),
     "vc_gelu_table_bf16": (c_int, [c_void_p, c_void_p]),
     "vc_patch_embed_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vc_mlp_weight_bytes": (c_size_t, [c_int, c_int]),
+    "vc_mlp_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    "vc_mlp_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "vc_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p]),
 }

@@ -17,6 +17,7 @@
 // to 4-vectors and the bf16 result leaves as 8-byte stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vitcolmap_hip.h"
 #include "common.h"
@@ -701,6 +702,605 @@ __global__ __launch_bounds__(256) void xs_prepare_kernel(const float* __restrict
   if (lane == 0) biasf[nfeat] = (b ? b[nfeat] : 0.f) + dot;
 }
 
+
+// =====================================================================================================
+// Fused MLP for 384-wide models:  x += fc2(gelu(fc1(LayerNorm(x))))  in ONE kernel, so the hidden tensor
+// (76 550 x 1536 bf16 = 235 MB, written by fc1 and read back by fc2: a third of a block's HBM traffic) never
+// exists and fc2 no longer stages both operands through L2 -> LDS.  Structure = the x-stationary kernel with a
+// second product per stage:
+//   * a wave keeps its 32 normalised token rows as B fragments (96 VGPRs) AND the 384 x 32 output tile of fc2 as
+//     12 accumulator tiles (192 VGPRs): one wave per SIMD (4 waves, 128 rows per workgroup, 512-register budget);
+//   * a stage is one 32-wide chunk of the hidden layer: 24 pieces of W1 (as in xs_kernel) + 24 pieces of W2
+//     (12 output blocks x 2 k-steps), 48 KiB, ring of 2;
+//   * per stage: H^T(32 hidden x 32 tokens) = W1c X^T (24 MFMAs, bias as initial value) -> GELU by the LDS table
+//     (integer work) -> the bf16 pairs ARE the B operand of Out^T += W2c^T-tile x G^T (24 MFMAs; accumulator tile as
+//     the next MFMA's operand: W2's k order is permuted by the prepare step to match the register order);
+//   * after the last chunk of a row tile: + fc2 bias + residual (the tile's own x rows, read back), stored in place.
+// Row tiles are dealt round-robin to one persistent workgroup per CU.
+constexpr int MStage = 2 * XStage;                 // 48 KiB: [W1 chunk | W2 chunk]
+constexpr int MNS = 2;
+constexpr int MOffB1 = MNS * MStage;               // fc1 bias (<= 2048 floats)
+constexpr int MOffGt = MOffB1 + 2048 * 4;          // GELU table (8704 B)
+constexpr int MOffB2 = MOffGt + 9216;              // fc2 bias (384 floats)
+constexpr int MOffTr = MOffB2 + 2048;              // per-wave transposers, 4 x 4 KiB
+constexpr int MLds = MOffTr + 4 * XChunk;          // 96 + 8 + 9 + 2 + 16 = 131 KiB
+
+__global__ __launch_bounds__(256, 1) void mlp_kernel(__bf16* __restrict__ X, const uint8_t* __restrict__ Wm,
+                                                     const float* __restrict__ b1f, const float* __restrict__ b2f,
+                                                     int M, int n_chunks, int n_tiles, float eps,
+                                                     const uint16_t* __restrict__ gelu_tab) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[MLds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int my_tiles = bid < n_tiles ? (n_tiles - bid + G - 1) / G : 0;
+  const int n = my_tiles * n_chunks;
+  if (n <= 0) return;
+
+  float* const b1_l = (float*)(lds + MOffB1);
+  float* const b2_l = (float*)(lds + MOffB2);
+  uint8_t* const gt_l = lds + MOffGt;
+  for (int i = tid; i < n_chunks * 32; i += 256) b1_l[i] = b1f[i];
+  for (int i = tid; i < XK; i += 256) b2_l[i] = b2f[i];
+  for (int i = tid; i < kGtBytes / 4; i += 256) ((uint32_t*)gt_l)[i] = ((const uint32_t*)gelu_tab)[i];
+
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0]);
+  // producer: wave w issues pieces 12w .. 12w+11 of every stage
+  auto issue = [&](int chunk, int slot) {
+    const uint8_t* src = Wm + (size_t)chunk * MStage + (size_t)(wave * 12) * 1024 + lane * 16;
+    const uint32_t dst = lds0 + (uint32_t)slot * MStage + (uint32_t)(wave * 12) * 1024u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src + i * 1024), "s"(dst + (uint32_t)i * 1024u)
+          : "memory");
+    }
+  };
+
+  // x rows of this wave: whole lines into registers, transposed to fragments through LDS, LayerNorm (see xs_kernel)
+  v8bf xf[XKS];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  uint8_t* const tp = lds + MOffTr + wave * XChunk;
+  const int prow = lane >> 3;
+  auto load_x = [&](int m0w) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(m0w + 8 * p + prow, M - 1);
+      const uint8_t* src = (const uint8_t*)X + (size_t)m * (XK * 2) + (lane & 7) * 16;
+#pragma unroll
+      for (int c = 0; c < XK / 64; ++c) *(v4u*)&xf[4 * c + p] = *(const v4u*)(src + c * 128);
+    }
+    const int fsw = (r >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < XK / 64; ++c) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = 8 * p + prow;
+        *(v4u*)(tp + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) = *(const v4u*)&xf[4 * c + p];
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        xf[4 * c + k4] = *(const v8bf*)(tp + r * 128 + (((2 * k4 + h) ^ fsw) << 4));
+    }
+    auto expand = [](uint32_t u) { return (v2f){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
+    v2f s2 = {0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < XKS; ++ks) {
+      const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s2 += expand(u[j]);
+    }
+    float sum = s2[0] + s2[1];
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / XK);
+    const v2f mean2 = {mean, mean};
+#pragma unroll
+    for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+    v2f q2 = {0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < XKS; ++ks) {
+      const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const v2f d = expand(u[j]) - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
+    }
+    float q = q2[0] + q2[1];
+    q += __shfl_xor(q, 32);
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / XK) + eps);
+    const v2f rstd2 = {rstd, rstd};
+#pragma unroll
+    for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+#pragma unroll
+    for (int ks = 0; ks < XKS; ++ks) {
+      const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const v2f y = (expand(u[j]) - mean2) * rstd2;
+        xf[ks][2 * j] = (__bf16)y[0];
+        xf[ks][2 * j + 1] = (__bf16)y[1];
+      }
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(X, 0, (int)((size_t)M * XK * 2), 0x00020000);
+  const int crow = lane >> 2, cch = lane & 3;
+  const int rsw = (r >> 2) & 3;
+  uint8_t* const tr_out = tp;
+  uint8_t* const tr_res = tp + 2048;
+
+  v16f oacc[12];
+  int tile = bid, chunk = 0, slot = 0;
+  issue(0, 0);
+  for (int i = 0; i < n; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + 1 < n) issue(chunk + 1 == n_chunks ? 0 : chunk + 1, slot ^ 1);   // into the slot read during iteration i-1
+    const int m0w = tile * 128 + wave * 32;
+    if (chunk == 0) {
+      load_x(m0w);
+#pragma unroll
+      for (int ob = 0; ob < 12; ++ob)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[ob][j] = 0.f;
+    }
+    const uint8_t* st = lds + slot * MStage + lane * 16;
+    // ---- fc1 chunk: H^T = W1c X^T, bias as the initial value --------------------------------------------
+    v16f hacc;
+    {
+      const float* bl = b1_l + chunk * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v4f bv = *(const v4f*)(bl + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hacc[4 * g + j] = bv[j];
+      }
+    }
+    {
+      constexpr int RD = 8;
+      v8bf wf[XKS];
+#pragma unroll
+      for (int ks = 0; ks < RD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
+#pragma unroll
+      for (int ks = 0; ks < XKS; ++ks) {
+#ifdef VC_MLP_NOFC1
+        if (ks > 0) { asm volatile("" :: "v"(wf[ks])); if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024); continue; }
+#endif
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
+        if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
+      }
+    }
+    // ---- GELU: bf16 pairs -> table (float path for a wave that holds a value outside the table) -----------
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    uint32_t gp[8];
+    {
+      uint32_t pb[8], gbad = 0;
+#pragma unroll
+      for (int qd = 0; qd < 8; ++qd) {
+        const v2bf pr = {(__bf16)hacc[2 * qd], (__bf16)hacc[2 * qd + 1]};
+        pb[qd] = *(const uint32_t*)&pr;
+      }
+      uint32_t g0[8], g1[8];
+#pragma unroll
+      for (int qd = 0; qd < 8; ++qd) {
+        const uint32_t b0 = pb[qd] & 0xffffu, b1 = pb[qd] >> 16;
+        const uint32_t k0 = (b0 & 0x7fffu) - kGtLo, k1 = (b1 & 0x7fffu) - kGtLo;
+        gbad = max(gbad, max(k0, k1));
+        g0[qd] = *(const uint16_t*)(gt_l + min(k0, kGtN - 1) * 4 + ((b0 >> 15) << 1));
+        g1[qd] = *(const uint16_t*)(gt_l + min(k1, kGtN - 1) * 4 + ((b1 >> 15) << 1));
+      }
+#ifdef VC_MLP_NOGELU
+      if (false) {
+#else
+      if (__any(gbad >= kGtN)) {
+#endif
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) {
+          const v2f_t y = gelu_erf2((v2f_t){__uint_as_float(pb[qd] << 16), __uint_as_float(pb[qd] & 0xffff0000u)});
+          const v2bf o = {(__bf16)y[0], (__bf16)y[1]};
+          gp[qd] = *(const uint32_t*)&o;
+        }
+      } else {
+#pragma unroll
+#ifdef VC_MLP_NOGELU
+        for (int qd = 0; qd < 8; ++qd) gp[qd] = pb[qd];
+#else
+        for (int qd = 0; qd < 8; ++qd) gp[qd] = g0[qd] | (g1[qd] << 16);
+#endif
+      }
+    }
+    // ---- fc2 partial: Out^T[12 x 32 features][32 tokens] += W2c G^T (registers 8s..8s+7 of the hidden tile are k-step s)
+    {
+      const v4u gA = {gp[0], gp[1], gp[2], gp[3]}, gB = {gp[4], gp[5], gp[6], gp[7]};
+      const v8bf g_s0 = *(const v8bf*)&gA, g_s1 = *(const v8bf*)&gB;
+      const uint8_t* st2 = st + XStage;
+      constexpr int RD = 8;
+      v8bf wf[24];
+#pragma unroll
+      for (int q = 0; q < RD; ++q) wf[q] = *(const v8bf*)(st2 + q * 1024);
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+#ifdef VC_MLP_NOFC2
+        if (q > 0) { asm volatile("" :: "v"(wf[q])); continue; }
+#endif
+        oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
+        if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
+      }
+    }
+    // ---- last chunk of the row tile: + fc2 bias + residual, in place ----------------------------------------
+    if (chunk == n_chunks - 1) {
+#pragma unroll
+      for (int ob = 0; ob < 12; ++ob) {
+        v4u resq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          resq[q] = *(const v4u*)(X + (size_t)min(m0w + crow + 16 * q, M - 1) * XK + ob * 32 + cch * 8);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = crow + 16 * q;
+          *(v4u*)(tr_res + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4)) = resq[q];
+        }
+        uint32_t ep[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const v4bf rv = *(const v4bf*)(tr_res + r * 64 + ((g ^ rsw) << 4) + 8 * h);
+          const v4f bv = *(const v4f*)(b2_l + ob * 32 + 8 * g + 4 * h);
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = oacc[ob][4 * g + j] + bv[j] + (float)rv[j];
+          const v2bf lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+          ep[2 * g] = *(const uint32_t*)&lo;
+          ep[2 * g + 1] = *(const uint32_t*)&hi;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(ep[k], ep[k + 4], false, false);
+          ep[k] = sw[0];
+          ep[k + 4] = sw[1];
+        }
+        *(v4u*)(tr_out + r * 64 + (((2 * h) ^ rsw) << 4)) = (v4u){ep[0], ep[1], ep[4], ep[5]};
+        *(v4u*)(tr_out + r * 64 + (((2 * h + 1) ^ rsw) << 4)) = (v4u){ep[2], ep[3], ep[6], ep[7]};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int row = crow + 16 * q;
+          const v4u o = *(const v4u*)(tr_out + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4));
+          __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, (int)(((size_t)(m0w + row) * XK + ob * 32 + cch * 8) * 2), 0, 0);
+        }
+      }
+      tile += G;
+    }
+    slot ^= 1;
+    chunk = chunk + 1 == n_chunks ? 0 : chunk + 1;
+  }
+}
+
+// Role-split form of the fused MLP (the one that is launched): 8 waves, two per SIMD.  Waves 0-3 ("A") keep the
+// normalised x rows and compute H^T chunk by chunk + the GELU; waves 4-7 ("B") keep the 384 x 32 output accumulators
+// and run fc2 one stage behind, taking the 32 x 32 bf16 activation tile of their partner (same SIMD, same 32 token rows)
+// through a 2 KiB LDS buffer.  Compared with one wave doing both (mlp_kernel above, kept for reference): both register
+// sets fit 256 VGPRs, so a SIMD holds an fc1 wave and an fc2 wave whose MFMA streams share the matrix pipe, the GELU's
+// integer work runs beside the partner's MFMAs, and the LDS-DMA pieces of a stage are issued by 8 waves instead of 4
+// (a piece occupies its wave for ~180 cycles: with 12 pieces per wave the staging alone took 2170 cycles per stage).
+// Stage i in the ring = [W1 chunk c_i | W2 chunk c_{i-1}] so both halves are consumed in iteration i.
+constexpr int M2OffB1 = MNS * MStage;                // fc1 bias, 1536 floats
+constexpr int M2OffGt = M2OffB1 + 1536 * 4;          // GELU table (8704 B)
+constexpr int M2OffB2 = M2OffGt + 8704;              // fc2 bias (384 floats)
+constexpr int M2OffTrA = M2OffB2 + 1536;             // x transposers of the A waves, 4 x 4 KiB
+constexpr int M2OffTrB = M2OffTrA + 4 * XChunk;      // out / residual transposers of the B waves, 4 x 4 KiB
+constexpr int M2OffG = M2OffTrB + 4 * XChunk;        // activation hand-off: [2 parities][4 pairs][2 KiB]
+constexpr int M2Lds = M2OffG + 2 * 4 * 2048;         // 96 + 16 + 16 + 16 + 16 = 160 KiB
+static_assert(M2Lds <= 160 * 1024, "fused MLP: LDS budget");
+
+__global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, const uint8_t* __restrict__ Wm,
+                                                      const float* __restrict__ b1f, const float* __restrict__ b2f,
+                                                      int M, int n_chunks, int n_tiles, float eps,
+                                                      const uint16_t* __restrict__ gelu_tab) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[M2Lds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool roleB = wave >= 4;
+  const int pairw = wave & 3;                       // row block of the pair inside the 128-row tile
+  const int r = lane & 31, h = lane >> 5;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int my_tiles = bid < n_tiles ? (n_tiles - bid + G - 1) / G : 0;
+  const int n = my_tiles * n_chunks;                // fc1 stages; fc2 runs one iteration behind
+  if (n <= 0) return;
+
+  float* const b1_l = (float*)(lds + M2OffB1);
+  float* const b2_l = (float*)(lds + M2OffB2);
+  uint8_t* const gt_l = lds + M2OffGt;
+  for (int i = tid; i < n_chunks * 32; i += 512) b1_l[i] = b1f[i];
+  for (int i = tid; i < XK; i += 512) b2_l[i] = b2f[i];
+  for (int i = tid; i < kGtBytes / 4; i += 512) ((uint32_t*)gt_l)[i] = ((const uint32_t*)gelu_tab)[i];
+
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0]);
+  // producer: waves 0-3 issue the W1 half of stage (chunk c1), waves 4-7 the W2 half (chunk c2), 6 pieces each
+  auto issue = [&](int c1, int c2, int slot) {
+    const int half = wave >> 2, q = wave & 3;
+    const int c = half ? c2 : c1;
+    const uint8_t* src = Wm + (size_t)c * MStage + (size_t)half * XStage + (size_t)(q * 6) * 1024 + lane * 16;
+    const uint32_t dst = lds0 + (uint32_t)slot * MStage + (uint32_t)half * XStage + (uint32_t)(q * 6) * 1024u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src + i * 1024), "s"(dst + (uint32_t)i * 1024u)
+          : "memory");
+    }
+  };
+  typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+
+  int chunk = 0, slot = 0, tile = bid;
+  issue(0, 0, 0);   // the W2 half of stage 0 is never read (clamped to chunk 0)
+  if (!roleB) {
+    // =========================== A: x rows, fc1, GELU ======================================================
+    v8bf xf[XKS];
+    uint8_t* const tp = lds + M2OffTrA + pairw * XChunk;
+    const int prow = lane >> 3;
+    for (int i = 0; i <= n; ++i) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (i >= n) break;                            // the extra iteration belongs to the B waves
+      {
+        const int cn = chunk + 1 == n_chunks ? 0 : chunk + 1;
+        issue(i + 1 < n ? cn : chunk, chunk, slot ^ 1);   // stage i+1 = [W1 c_{i+1} | W2 c_i]
+      }
+      if (chunk == 0) {
+        const int m0w = tile * 128 + pairw * 32;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = min(m0w + 8 * p + prow, M - 1);
+          const uint8_t* src = (const uint8_t*)X + (size_t)m * (XK * 2) + (lane & 7) * 16;
+#pragma unroll
+          for (int c = 0; c < XK / 64; ++c) *(v4u*)&xf[4 * c + p] = *(const v4u*)(src + c * 128);
+        }
+        const int fsw = (r >> 1) & 7;
+#pragma unroll
+        for (int c = 0; c < XK / 64; ++c) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int row = 8 * p + prow;
+            *(v4u*)(tp + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) = *(const v4u*)&xf[4 * c + p];
+          }
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4)
+            xf[4 * c + k4] = *(const v8bf*)(tp + r * 128 + (((2 * k4 + h) ^ fsw) << 4));
+        }
+        auto expand = [](uint32_t u) { return (v2f){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
+        v2f s2 = {0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) {
+          const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s2 += expand(u[j]);
+        }
+        float sum = s2[0] + s2[1];
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / XK);
+        const v2f mean2 = {mean, mean};
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+        v2f q2 = {0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) {
+          const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const v2f d = expand(u[j]) - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
+        }
+        float q = q2[0] + q2[1];
+        q += __shfl_xor(q, 32);
+        const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / XK) + eps);
+        const v2f rstd2 = {rstd, rstd};
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) {
+          const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const v2f y = (expand(u[j]) - mean2) * rstd2;
+            xf[ks][2 * j] = (__bf16)y[0];
+            xf[ks][2 * j + 1] = (__bf16)y[1];
+          }
+        }
+      }
+      const uint8_t* st = lds + slot * MStage + lane * 16;
+      v16f hacc;
+      {
+        const float* bl = b1_l + chunk * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const v4f bv = *(const v4f*)(bl + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hacc[4 * g + j] = bv[j];
+        }
+      }
+      {
+        constexpr int RD = 8;
+        v8bf wf[XKS];
+#pragma unroll
+        for (int ks = 0; ks < RD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) {
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
+          if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
+        }
+      }
+      uint32_t gp[8];
+      {
+        uint32_t pb[8], gbad = 0, g0[8], g1[8];
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) {
+          const v2bf pr = {(__bf16)hacc[2 * qd], (__bf16)hacc[2 * qd + 1]};
+          pb[qd] = *(const uint32_t*)&pr;
+        }
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) {
+          const uint32_t b0 = pb[qd] & 0xffffu, b1 = pb[qd] >> 16;
+          const uint32_t k0 = (b0 & 0x7fffu) - kGtLo, k1 = (b1 & 0x7fffu) - kGtLo;
+          gbad = max(gbad, max(k0, k1));
+          g0[qd] = *(const uint16_t*)(gt_l + min(k0, kGtN - 1) * 4 + ((b0 >> 15) << 1));
+          g1[qd] = *(const uint16_t*)(gt_l + min(k1, kGtN - 1) * 4 + ((b1 >> 15) << 1));
+        }
+        if (__any(gbad >= kGtN)) {
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd) {
+            const v2f_t y = gelu_erf2((v2f_t){__uint_as_float(pb[qd] << 16), __uint_as_float(pb[qd] & 0xffff0000u)});
+            const v2bf o = {(__bf16)y[0], (__bf16)y[1]};
+            gp[qd] = *(const uint32_t*)&o;
+          }
+        } else {
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd) gp[qd] = g0[qd] | (g1[qd] << 16);
+        }
+      }
+      // hand the activation tile to the partner: two 16-byte vectors per lane (k-step 0, k-step 1)
+      uint8_t* const gb = lds + M2OffG + ((i & 1) * 4 + pairw) * 2048 + lane * 16;
+      *(v4u*)gb = (v4u){gp[0], gp[1], gp[2], gp[3]};
+      *(v4u*)(gb + 1024) = (v4u){gp[4], gp[5], gp[6], gp[7]};
+      slot ^= 1;
+      if (++chunk == n_chunks) { chunk = 0; tile += G; }
+    }
+  } else {
+    // =========================== B: fc2 accumulators, one stage behind, tile epilogue ==========================
+    v16f oacc[12];
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(X, 0, (int)((size_t)M * XK * 2), 0x00020000);
+    const int crow = lane >> 2, cch = lane & 3;
+    const int rsw = (r >> 2) & 3;
+    uint8_t* const tr_out = lds + M2OffTrB + pairw * XChunk;
+    uint8_t* const tr_res = tr_out + 2048;
+    int pchunk = 0;                                  // chunk consumed in this iteration (= c_{i-1})
+    for (int i = 0; i <= n; ++i) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (i < n) {
+        const int cn = chunk + 1 == n_chunks ? 0 : chunk + 1;
+        issue(i + 1 < n ? cn : chunk, chunk, slot ^ 1);
+      }
+      if (i > 0) {
+        if (pchunk == 0) {
+#pragma unroll
+          for (int ob = 0; ob < 12; ++ob)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) oacc[ob][j] = 0.f;
+        }
+        const uint8_t* gb = lds + M2OffG + (((i - 1) & 1) * 4 + pairw) * 2048 + lane * 16;
+        const v8bf g_s0 = *(const v8bf*)gb, g_s1 = *(const v8bf*)(gb + 1024);
+        const uint8_t* st2 = lds + slot * MStage + XStage + lane * 16;
+        {
+          constexpr int RD = 6;
+          v8bf wf[24];
+#pragma unroll
+          for (int q = 0; q < RD; ++q) wf[q] = *(const v8bf*)(st2 + q * 1024);
+#pragma unroll
+          for (int q = 0; q < 24; ++q) {
+            oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
+            if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
+          }
+        }
+        if (pchunk == n_chunks - 1) {
+          const int m0w = tile * 128 + pairw * 32;
+#pragma unroll 1
+          for (int ob = 0; ob < 12; ++ob) {
+            v4u resq[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              resq[q] = *(const v4u*)(X + (size_t)min(m0w + crow + 16 * q, M - 1) * XK + ob * 32 + cch * 8);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int row = crow + 16 * q;
+              *(v4u*)(tr_res + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4)) = resq[q];
+            }
+            v16f oa;
+            switch (ob) {   // dynamic index into the register tiles
+#define VC_OB(k) case k: oa = oacc[k]; break;
+              VC_OB(0) VC_OB(1) VC_OB(2) VC_OB(3) VC_OB(4) VC_OB(5) VC_OB(6) VC_OB(7) VC_OB(8) VC_OB(9) VC_OB(10)
+              default: oa = oacc[11]; break;
+#undef VC_OB
+            }
+            uint32_t ep[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const v4bf rv = *(const v4bf*)(tr_res + r * 64 + ((g ^ rsw) << 4) + 8 * h);
+              const v4f bv = *(const v4f*)(b2_l + ob * 32 + 8 * g + 4 * h);
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = oa[4 * g + j] + bv[j] + (float)rv[j];
+              const v2bf lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+              ep[2 * g] = *(const uint32_t*)&lo;
+              ep[2 * g + 1] = *(const uint32_t*)&hi;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(ep[k], ep[k + 4], false, false);
+              ep[k] = sw[0];
+              ep[k + 4] = sw[1];
+            }
+            *(v4u*)(tr_out + r * 64 + (((2 * h) ^ rsw) << 4)) = (v4u){ep[0], ep[1], ep[4], ep[5]};
+            *(v4u*)(tr_out + r * 64 + (((2 * h + 1) ^ rsw) << 4)) = (v4u){ep[2], ep[3], ep[6], ep[7]};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int row = crow + 16 * q;
+              const v4u o = *(const v4u*)(tr_out + row * 64 + ((cch ^ ((row >> 2) & 3)) << 4));
+              __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, (int)(((size_t)(m0w + row) * XK + ob * 32 + cch * 8) * 2), 0, 0);
+            }
+          }
+          tile += G;
+        }
+        if (++pchunk == n_chunks) pchunk = 0;
+      }
+      slot ^= 1;
+      if (i < n && ++chunk == n_chunks) chunk = 0;
+    }
+  }
+}
+
+// MLP weights -> stage order: chunk c = [24 pieces of W1' (features 32c..+32, LayerNorm gamma folded) | 24 pieces of W2
+// (piece 2 ob + s: output features 32 ob..+32, hidden 32c + 16s + 8(j>>2) + 4h + (j&3) in element j of lane 32h + r)].
+__global__ __launch_bounds__(256) void mlp_prepare_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ W2, const float* __restrict__ b2,
+                                                          int n_hid, __bf16* __restrict__ Wm, float* __restrict__ b1f,
+                                                          float* __restrict__ b2f) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);   // hidden feature (fc1 part), then output feature (fc2 part)
+  if (unit < n_hid) {
+    const int c = unit >> 5, rr = unit & 31;
+    float dot = 0.f;
+    for (int k = lane; k < XK; k += 64) {
+      const float w = W1[(size_t)unit * XK + k];
+      if (beta) dot += w * beta[k];
+      const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
+      Wm[(size_t)c * (MStage / 2) + ((size_t)ks * 64 + hh * 32 + rr) * 8 + j] = (__bf16)(gamma ? w * gamma[k] : w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (lane == 0) b1f[unit] = (b1 ? b1[unit] : 0.f) + dot;
+  } else if (unit < n_hid + XK) {
+    const int f = unit - n_hid, ob = f >> 5, rr = f & 31;
+    for (int hd = lane; hd < n_hid; hd += 64) {
+      const int c = hd >> 5, e = hd & 31, s = e >> 4, e16 = e & 15;
+      // e16 = 8 (j >> 2) + 4 h + (j & 3)
+      const int hh = (e16 >> 2) & 1, j = ((e16 >> 3) << 2) | (e16 & 3);
+      Wm[(size_t)c * (MStage / 2) + (XStage / 2) + ((size_t)(2 * ob + s) * 64 + hh * 32 + rr) * 8 + j] = (__bf16)W2[(size_t)f * n_hid + hd];
+    }
+    if (lane == 0) b2f[f] = b2 ? b2[f] : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -814,6 +1414,45 @@ int vc_patch_embed_bf16(const void* patches, const void* weight, const void* bia
   hipLaunchKernelGGL(gemm_kernel<EPI_PATCH>, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, (const __bf16*)patches,
                      (const __bf16*)weight, (const __bf16*)bias, (const __bf16*)pos_embed, (__bf16*)out, (int)rows, n_out,
                      k_in, n_out / BN, (int)nt, tokens);
+  return vc::check_launch();
+}
+
+
+size_t vc_mlp_weight_bytes(int n_hidden, int dim) {
+  if (dim != XK || n_hidden <= 0 || n_hidden % 32 != 0 || n_hidden > 2048) return 0;
+  return (size_t)(n_hidden / 32) * MStage;
+}
+
+int vc_mlp_prepare(const float* w1, const float* b1_or_null, const float* ln_gamma_or_null, const float* ln_beta_or_null,
+                   const float* w2, const float* b2_or_null, int n_hidden, int dim, void* weights_tiled, float* b1_folded,
+                   float* b2_out, vc_stream_t stream) {
+  if (!w1 || !w2 || !weights_tiled || !b1_folded || !b2_out) return VC_ERR_INVALID_ARG;
+  if (vc_mlp_weight_bytes(n_hidden, dim) == 0) return VC_ERR_UNSUPPORTED;
+  if ((ln_gamma_or_null == nullptr) != (ln_beta_or_null == nullptr)) return VC_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(mlp_prepare_kernel, dim3((n_hidden + XK + 3) / 4), dim3(256), 0, (hipStream_t)stream, w1, b1_or_null,
+                     ln_gamma_or_null, ln_beta_or_null, w2, b2_or_null, n_hidden, (__bf16*)weights_tiled, b1_folded, b2_out);
+  return vc::check_launch();
+}
+
+int vc_mlp_bf16(void* x_inout, const void* weights_tiled, const float* b1_folded, const float* b2, const void* gelu_table,
+                int rows, int n_hidden, int dim, float ln_eps, vc_stream_t stream) {
+  if (!x_inout || !weights_tiled || !b1_folded || !b2 || !gelu_table || rows < 0) return VC_ERR_INVALID_ARG;
+  if (vc_mlp_weight_bytes(n_hidden, dim) == 0) return VC_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x_inout) | ((uintptr_t)weights_tiled) | ((uintptr_t)b1_folded) | ((uintptr_t)b2) | ((uintptr_t)gelu_table)) % 16 != 0)
+    return VC_ERR_INVALID_ARG;
+  if (rows == 0) return VC_OK;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return vc::fail(hipErrorInvalidDevice);
+  const int n_tiles = (rows + 127) / 128;
+  const dim3 grid((unsigned)(n_tiles < cus ? n_tiles : cus));
+  static const bool single = [] { const char* e = getenv("VITCOLMAP_MLP_SINGLE"); return e && atoi(e) != 0; }();   // developer A/B switch
+  if (single || n_hidden > 1536)
+    hipLaunchKernelGGL(mlp_kernel, grid, dim3(256), 0, (hipStream_t)stream, (__bf16*)x_inout, (const uint8_t*)weights_tiled, b1_folded,
+                       b2, rows, n_hidden / 32, n_tiles, ln_eps, (const uint16_t*)gelu_table);
+  else
+    hipLaunchKernelGGL(mlp2_kernel, grid, dim3(512), 0, (hipStream_t)stream, (__bf16*)x_inout, (const uint8_t*)weights_tiled, b1_folded,
+                       b2, rows, n_hidden / 32, n_tiles, ln_eps, (const uint16_t*)gelu_table);
   return vc::check_launch();
 }
 

@@ -12,9 +12,10 @@ MI355X-first choices
   * the image is consumed already patchified, (B, Hp*Wp, 3*14*14) or zero padded to 640: the HIP preprocessing
     kernel (csrc/preprocess.hip) writes that layout directly, so the patch embedding is ONE GEMM instead of a
     strided 14x14 convolution;
-  * ViT-S (`_blocks_hip`): patch + position embedding, LN1+qkv, proj+residual, LN2+fc1+GELU, fc2+residual are
-    hand-written bf16 MFMA GEMMs with fused prologues / epilogues, the attention a hand-written flash kernel —
-    five kernels per block, no library GEMM and no standalone elementwise pass;
+  * ViT-S (`_blocks_hip`): patch + position embedding, LN1+qkv, proj+residual and the whole MLP
+    (LN2+fc1+GELU+fc2+residual, the hidden tensor never leaves the chip) are hand-written bf16 MFMA kernels with fused
+    prologues / epilogues, the attention a hand-written flash kernel — four kernels per block, no library GEMM and no
+    standalone elementwise pass;
   * other widths (`_blocks_fused`): `F.linear` (hipBLASLt) + the fused add+LayerNorm and attention kernels;
     plain `nn.Module` path (`Block.forward`, SDPA) on the CPU / in float32 — the oracle-side evaluation;
   * LayerScale is folded into the projection weights at load time, LayerNorm gamma / beta into the GEMM that
@@ -251,7 +252,9 @@ class DinoV2(nn.Module):
         qkv with norm1 folded in, proj, fc1 with norm2 folded in.  Call it while the parameters are still
         float32 (after fold_layerscale, on the GPU) so gamma is folded before the one rounding to bf16;
         `_blocks_fused` calls it lazily otherwise.  Only the 384-wide MLP models (ViT-S) are covered."""
-        from .hip_ops import XsLinear
+        import os
+
+        from .hip_ops import FusedMlp, XsLinear
         from .hip_ops import gelu_table as hip_ops_gelu_table
 
         self._hip = False
@@ -264,10 +267,13 @@ class DinoV2(nn.Module):
         wp[:, : w.shape[1]] = w
         self._pe_w = wp.to(torch.bfloat16).contiguous()          # conv weight as a [C][640] GEMM operand (zero padded K)
         self._gelu_tab = hip_ops_gelu_table(w.device)
+        self._use_fused_mlp = os.environ.get("VITCOLMAP_FUSED_MLP", "1") == "1"   # developer A/B switch: 0 = fc1 and fc2 as two kernels
         self._hip = [dict(
             qkv=XsLinear(*_prescale_q(b.attn.qkv.weight, b.attn.qkv.bias, self.arch.dim), b.norm1.weight, b.norm1.bias, b.norm1.eps),
             proj=XsLinear(b.attn.proj.weight, b.attn.proj.bias),
             fc1=XsLinear(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm2.weight, b.norm2.bias, b.norm2.eps),
+            mlp=FusedMlp(b.mlp.fc1.weight, b.mlp.fc1.bias, b.norm2.weight, b.norm2.bias, b.mlp.fc2.weight, b.mlp.fc2.bias,
+                         b.norm2.eps) if self._use_fused_mlp else None,
         ) for b in self.blocks]
         return self
 
@@ -279,6 +285,9 @@ class DinoV2(nn.Module):
         for blk, hw in zip(self.blocks, self._hip):
             a = ops.attention(hw["qkv"](x), blk.attn.num_heads, q_prescaled=True)   # LN1 + qkv (q pre-scaled), flash attention
             hw["proj"](a, ops.EPI_RESIDUAL, residual=x, out=x)            # x += proj(a)
+            if hw["mlp"] is not None:
+                hw["mlp"](x)                                              # x += fc2(gelu(fc1(LN2 x))), one kernel
+                continue
             hdn = hw["fc1"](x, ops.EPI_GELU, gelu_table=self._gelu_tab)   # gelu(fc1(LN2 x)), GELU by LDS table
             fc2 = blk.mlp.fc2
             ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=x, out=x)   # x += fc2(hdn)

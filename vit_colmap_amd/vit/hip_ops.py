@@ -129,3 +129,33 @@ def gelu_table(device) -> torch.Tensor:
         _lib.check(lib.vc_gelu_table_bf16(_lib.ptr(t), _lib.stream_ptr()), "vc_gelu_table_bf16")
         _GELU_TABLES[key] = t
     return _GELU_TABLES[key]
+
+
+class FusedMlp:
+    """x += fc2(gelu(fc1(LayerNorm(x)))) in one kernel (csrc/gemm.hip, mlp_kernel), dim 384.  Built once from
+    float32 parameters (fc2 with LayerScale already folded in); call with the bf16 residual stream, updated in place."""
+
+    def __init__(self, w1, b1, ln_weight, ln_bias, w2, b2, ln_eps: float = 1e-6):
+        lib = _lib.load()
+        n_hid, dim = w1.shape
+        nbytes = lib.vc_mlp_weight_bytes(n_hid, dim)
+        if nbytes == 0 or tuple(w2.shape) != (dim, n_hid):
+            raise _lib.HipLibraryError(f"vc_mlp: unsupported shape {n_hid}x{dim}")
+        dev = w1.device
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        w1f, b1f, g, be, w2f, b2f = f(w1), f(b1), f(ln_weight), f(ln_bias), f(w2), f(b2)
+        self.n_hid, self.dim, self.eps = n_hid, dim, float(ln_eps)
+        self.wm = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.b1 = torch.empty(n_hid, dtype=torch.float32, device=dev)
+        self.b2 = torch.empty(dim, dtype=torch.float32, device=dev)
+        self.table = gelu_table(dev)
+        _lib.check(lib.vc_mlp_prepare(_lib.ptr(w1f), _lib.ptr(b1f), _lib.ptr(g), _lib.ptr(be), _lib.ptr(w2f), _lib.ptr(b2f),
+                                      n_hid, dim, _lib.ptr(self.wm), _lib.ptr(self.b1), _lib.ptr(self.b2), _lib.stream_ptr()),
+                   "vc_mlp_prepare")
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == self.dim
+        lib = _lib.load()
+        _lib.check(lib.vc_mlp_bf16(_lib.ptr(x), _lib.ptr(self.wm), _lib.ptr(self.b1), _lib.ptr(self.b2), _lib.ptr(self.table),
+                                   x.numel() // self.dim, self.n_hid, self.dim, self.eps, _lib.stream_ptr()), "vc_mlp_bf16")
+        return x
