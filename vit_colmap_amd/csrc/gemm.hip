@@ -1043,161 +1043,201 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
   typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
   typedef float v2f __attribute__((ext_vector_type(2)));
 
+  // Iteration i (0 .. n+1) works on ring stage i = [W1 chunk of fc1 stage i | W2 chunk of fc1 stage i-2]:
+  //   A waves: MFMAs of fc1 stage i, with the GELU of stage i-1 (integer work + LDS gathers, which overlap with MFMAs
+  //            in the same wave) issued in slices between them; the activation tile of stage i-1 is handed over at the end;
+  //   B waves: fc2 partial product with the activation tile of stage i-2.
   int chunk = 0, slot = 0, tile = bid;
-  issue(0, 0, 0);   // the W2 half of stage 0 is never read (clamped to chunk 0)
+  auto chunk_of = [&](int j) { return j % n_chunks; };
+  auto issue_stage = [&](int j, int slot_) {        // stage j; clamped chunks stage data nobody reads
+    const int c1 = chunk_of(min(max(j, 0), n - 1)), c2 = chunk_of(min(max(j - 2, 0), n - 1));
+    issue(c1, c2, slot_);
+  };
+#ifdef VC_MLP_STAMP
+  uint32_t st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t st_t0 = __builtin_amdgcn_s_memtime();
+  uint64_t st_prev = st_t0;
+#define MS(k_) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); st_c[k_] += (uint32_t)(t_ - st_prev); st_prev = t_; }
+#else
+#define MS(k_)
+#endif
+  issue_stage(0, 0);
   if (!roleB) {
     // =========================== A: x rows, fc1, GELU ======================================================
     v8bf xf[XKS];
     uint8_t* const tp = lds + M2OffTrA + pairw * XChunk;
     const int prow = lane >> 3;
-    for (int i = 0; i <= n; ++i) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (i >= n) break;                            // the extra iteration belongs to the B waves
-      {
-        const int cn = chunk + 1 == n_chunks ? 0 : chunk + 1;
-        issue(i + 1 < n ? cn : chunk, chunk, slot ^ 1);   // stage i+1 = [W1 c_{i+1} | W2 c_i]
+    v16f hprev;                                      // pre-activations of stage i-1
+    uint32_t pb[8], gq[8], gres[8], gbad = 0;        // GELU state flowing from slice to slice
+    auto gelu_slice = [&](int sl, int parity) {
+      if (sl < 4) {                                  // bf16 pairs of the pre-activations (the only float work)
+        const int g = sl;
+        const v2bf lo = {(__bf16)hprev[4 * g], (__bf16)hprev[4 * g + 1]}, hi = {(__bf16)hprev[4 * g + 2], (__bf16)hprev[4 * g + 3]};
+        pb[2 * g] = *(const uint32_t*)&lo;
+        pb[2 * g + 1] = *(const uint32_t*)&hi;
+        if (sl == 0) gbad = 0;
       }
-      if (chunk == 0) {
-        const int m0w = tile * 128 + pairw * 32;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int m = min(m0w + 8 * p + prow, M - 1);
-          const uint8_t* src = (const uint8_t*)X + (size_t)m * (XK * 2) + (lane & 7) * 16;
-#pragma unroll
-          for (int c = 0; c < XK / 64; ++c) *(v4u*)&xf[4 * c + p] = *(const v4u*)(src + c * 128);
-        }
-        const int fsw = (r >> 1) & 7;
-#pragma unroll
-        for (int c = 0; c < XK / 64; ++c) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const int row = 8 * p + prow;
-            *(v4u*)(tp + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) = *(const v4u*)&xf[4 * c + p];
-          }
-#pragma unroll
-          for (int k4 = 0; k4 < 4; ++k4)
-            xf[4 * c + k4] = *(const v8bf*)(tp + r * 128 + (((2 * k4 + h) ^ fsw) << 4));
-        }
-        auto expand = [](uint32_t u) { return (v2f){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
-        v2f s2 = {0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < XKS; ++ks) {
-          const v4u u = *(const v4u*)&xf[ks];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) s2 += expand(u[j]);
-        }
-        float sum = s2[0] + s2[1];
-        sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / XK);
-        const v2f mean2 = {mean, mean};
-#pragma unroll
-        for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
-        v2f q2 = {0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < XKS; ++ks) {
-          const v4u u = *(const v4u*)&xf[ks];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { const v2f d = expand(u[j]) - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
-        }
-        float q = q2[0] + q2[1];
-        q += __shfl_xor(q, 32);
-        const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / XK) + eps);
-        const v2f rstd2 = {rstd, rstd};
-#pragma unroll
-        for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
-#pragma unroll
-        for (int ks = 0; ks < XKS; ++ks) {
-          const v4u u = *(const v4u*)&xf[ks];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const v2f y = (expand(u[j]) - mean2) * rstd2;
-            xf[ks][2 * j] = (__bf16)y[0];
-            xf[ks][2 * j + 1] = (__bf16)y[1];
-          }
-        }
+      if (sl >= 4 && sl < 12) {                      // table index + LDS gather of packed register sl-4
+        const int qd = sl - 4;
+        const uint32_t b0 = pb[qd] & 0xffffu, b1 = pb[qd] >> 16;
+        const uint32_t k0 = (b0 & 0x7fffu) - kGtLo, k1 = (b1 & 0x7fffu) - kGtLo;
+        gbad = max(gbad, max(k0, k1));
+        gq[2 * (qd & 3)] = *(const uint16_t*)(gt_l + min(k0, kGtN - 1) * 4 + ((b0 >> 15) << 1));
+        gq[2 * (qd & 3) + 1] = *(const uint16_t*)(gt_l + min(k1, kGtN - 1) * 4 + ((b1 >> 15) << 1));
       }
-      const uint8_t* st = lds + slot * MStage + lane * 16;
-      v16f hacc;
-      {
-        const float* bl = b1_l + chunk * 32 + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const v4f bv = *(const v4f*)(bl + 8 * g);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) hacc[4 * g + j] = bv[j];
-        }
+      if (sl >= 7 && sl < 15) {                      // three slices after the gather was issued
+        const int qd = sl - 7;
+        gres[qd] = gq[2 * (qd & 3)] | (gq[2 * (qd & 3) + 1] << 16);
       }
-      {
-        constexpr int RD = 8;
-        v8bf wf[XKS];
-#pragma unroll
-        for (int ks = 0; ks < RD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
-#pragma unroll
-        for (int ks = 0; ks < XKS; ++ks) {
-          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
-          if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
-        }
-      }
-      uint32_t gp[8];
-      {
-        uint32_t pb[8], gbad = 0, g0[8], g1[8];
-#pragma unroll
-        for (int qd = 0; qd < 8; ++qd) {
-          const v2bf pr = {(__bf16)hacc[2 * qd], (__bf16)hacc[2 * qd + 1]};
-          pb[qd] = *(const uint32_t*)&pr;
-        }
-#pragma unroll
-        for (int qd = 0; qd < 8; ++qd) {
-          const uint32_t b0 = pb[qd] & 0xffffu, b1 = pb[qd] >> 16;
-          const uint32_t k0 = (b0 & 0x7fffu) - kGtLo, k1 = (b1 & 0x7fffu) - kGtLo;
-          gbad = max(gbad, max(k0, k1));
-          g0[qd] = *(const uint16_t*)(gt_l + min(k0, kGtN - 1) * 4 + ((b0 >> 15) << 1));
-          g1[qd] = *(const uint16_t*)(gt_l + min(k1, kGtN - 1) * 4 + ((b1 >> 15) << 1));
-        }
-        if (__any(gbad >= kGtN)) {
+      if (sl == 15) {
+        if (__any(gbad >= kGtN)) {                   // a value outside the table somewhere in the wave: float path
 #pragma unroll
           for (int qd = 0; qd < 8; ++qd) {
             const v2f_t y = gelu_erf2((v2f_t){__uint_as_float(pb[qd] << 16), __uint_as_float(pb[qd] & 0xffff0000u)});
             const v2bf o = {(__bf16)y[0], (__bf16)y[1]};
-            gp[qd] = *(const uint32_t*)&o;
+            gres[qd] = *(const uint32_t*)&o;
           }
-        } else {
-#pragma unroll
-          for (int qd = 0; qd < 8; ++qd) gp[qd] = g0[qd] | (g1[qd] << 16);
         }
       }
-      // hand the activation tile to the partner: two 16-byte vectors per lane (k-step 0, k-step 1)
-      uint8_t* const gb = lds + M2OffG + ((i & 1) * 4 + pairw) * 2048 + lane * 16;
-      *(v4u*)gb = (v4u){gp[0], gp[1], gp[2], gp[3]};
-      *(v4u*)(gb + 1024) = (v4u){gp[4], gp[5], gp[6], gp[7]};
+      if (sl == 16) {                                // hand the activation tile to the partner (k-step 0, k-step 1)
+        uint8_t* const gb = lds + M2OffG + (parity * 4 + pairw) * 2048 + lane * 16;
+        *(v4u*)gb = (v4u){gres[0], gres[1], gres[2], gres[3]};
+        *(v4u*)(gb + 1024) = (v4u){gres[4], gres[5], gres[6], gres[7]};
+      }
+    };
+    for (int i = 0; i <= n + 1; ++i) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      MS(0)
+      if (i <= n) issue_stage(i + 1, slot ^ 1);
+      MS(1)
+      if (i < n) {
+        if (chunk == 0) {
+          const int m0w = tile * 128 + pairw * 32;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int m = min(m0w + 8 * p + prow, M - 1);
+            const uint8_t* src = (const uint8_t*)X + (size_t)m * (XK * 2) + (lane & 7) * 16;
+#pragma unroll
+            for (int c = 0; c < XK / 64; ++c) *(v4u*)&xf[4 * c + p] = *(const v4u*)(src + c * 128);
+          }
+          const int fsw = (r >> 1) & 7;
+#pragma unroll
+          for (int c = 0; c < XK / 64; ++c) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const int row = 8 * p + prow;
+              *(v4u*)(tp + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) = *(const v4u*)&xf[4 * c + p];
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+              xf[4 * c + k4] = *(const v8bf*)(tp + r * 128 + (((2 * k4 + h) ^ fsw) << 4));
+          }
+          auto expand = [](uint32_t u) { return (v2f){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
+          v2f s2 = {0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks) {
+            const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s2 += expand(u[j]);
+          }
+          float sum = s2[0] + s2[1];
+          sum += __shfl_xor(sum, 32);
+          const float mean = sum * (1.0f / XK);
+          const v2f mean2 = {mean, mean};
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+          v2f q2 = {0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks) {
+            const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const v2f d = expand(u[j]) - mean2; q2 = __builtin_elementwise_fma(d, d, q2); }
+          }
+          float q = q2[0] + q2[1];
+          q += __shfl_xor(q, 32);
+          const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / XK) + eps);
+          const v2f rstd2 = {rstd, rstd};
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks) {
+            const v4u u = *(const v4u*)&xf[ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const v2f y = (expand(u[j]) - mean2) * rstd2;
+              xf[ks][2 * j] = (__bf16)y[0];
+              xf[ks][2 * j + 1] = (__bf16)y[1];
+            }
+          }
+        }
+        MS(2)
+        const uint8_t* st = lds + slot * MStage + lane * 16;
+        v16f hacc;
+        {
+          const float* bl = b1_l + chunk * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const v4f bv = *(const v4f*)(bl + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hacc[4 * g + j] = bv[j];
+          }
+        }
+        {
+          constexpr int RD = 6;
+          v8bf wf[XKS];
+#pragma unroll
+          for (int ks = 0; ks < RD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i > 0) {
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) {
+              hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
+              if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
+              gelu_slice(ks, (i - 1) & 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) {
+              hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
+              if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        hprev = hacc;
+        MS(3)
+        if (++chunk == n_chunks) { chunk = 0; tile += G; }
+      } else if (i == n) {
+        // the last stage's GELU has no MFMAs to ride under
+#pragma unroll
+        for (int sl = 0; sl < XKS; ++sl) gelu_slice(sl, (i - 1) & 1);
+        MS(4)
+      }
       slot ^= 1;
-      if (++chunk == n_chunks) { chunk = 0; tile += G; }
     }
   } else {
-    // =========================== B: fc2 accumulators, one stage behind, tile epilogue ==========================
+    // =========================== B: fc2 accumulators, two stages behind, tile epilogue ==========================
     v16f oacc[12];
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(X, 0, (int)((size_t)M * XK * 2), 0x00020000);
     const int crow = lane >> 2, cch = lane & 3;
     const int rsw = (r >> 2) & 3;
     uint8_t* const tr_out = lds + M2OffTrB + pairw * XChunk;
     uint8_t* const tr_res = tr_out + 2048;
-    int pchunk = 0;                                  // chunk consumed in this iteration (= c_{i-1})
-    for (int i = 0; i <= n; ++i) {
+    int pchunk = 0;                                  // chunk consumed in this iteration (that of fc1 stage i-2)
+    for (int i = 0; i <= n + 1; ++i) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (i < n) {
-        const int cn = chunk + 1 == n_chunks ? 0 : chunk + 1;
-        issue(i + 1 < n ? cn : chunk, chunk, slot ^ 1);
-      }
-      if (i > 0) {
+      MS(0)
+      if (i >= 2) {
         if (pchunk == 0) {
 #pragma unroll
           for (int ob = 0; ob < 12; ++ob)
 #pragma unroll
             for (int j = 0; j < 16; ++j) oacc[ob][j] = 0.f;
         }
-        const uint8_t* gb = lds + M2OffG + (((i - 1) & 1) * 4 + pairw) * 2048 + lane * 16;
+        const uint8_t* gb = lds + M2OffG + ((i & 1) * 4 + pairw) * 2048 + lane * 16;   // parity of stage i-2
         const v8bf g_s0 = *(const v8bf*)gb, g_s1 = *(const v8bf*)(gb + 1024);
         const uint8_t* st2 = lds + slot * MStage + XStage + lane * 16;
         {
@@ -1211,6 +1251,10 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
             if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
           }
         }
+#ifdef VC_MLP_STAMP
+        asm volatile("s_nop 0" :: "v"(oacc[11]));
+#endif
+        MS(3)
         if (pchunk == n_chunks - 1) {
           const int m0w = tile * 128 + pairw * 32;
 #pragma unroll 1
@@ -1261,11 +1305,25 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           tile += G;
         }
         if (++pchunk == n_chunks) pchunk = 0;
+        MS(5)
       }
+      // the W2 half of the next stage is issued AFTER this wave's MFMAs: its partner issues the W1 half BEFORE its own
+      if (i <= n) issue_stage(i + 1, slot ^ 1);
+      MS(1)
       slot ^= 1;
-      if (i < n && ++chunk == n_chunks) chunk = 0;
     }
   }
+#ifdef VC_MLP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  st_c[7] = (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0);
+  if (lane < 8) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) v = lane == kq ? st_c[kq] : v;
+    ((uint32_t*)X)[(bid * 8 + wave) * 8 + lane] = v;   // diagnostic build: overwrites the first rows of x
+  }
+#endif
 }
 
 // MLP weights -> stage order: chunk c = [24 pieces of W1' (features 32c..+32, LayerNorm gamma folded) | 24 pieces of W2
