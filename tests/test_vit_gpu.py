@@ -248,7 +248,7 @@ def test_attention_prescaled_q_lazy_max(B, N, H, spread):
     assert float(err.max()) < 3e-2 and float((out - ref).norm() / ref.norm()) < 1e-2, (float(err.max()), float((out - ref).norm() / ref.norm()))
 
 
-@pytest.mark.parametrize("rows", [1, 127, 128, 300, 1531 * 3, 128 * 256 + 128 * 3 + 5])
+@pytest.mark.parametrize("rows", [1, 127, 128, 300, 1531 * 3, 128 * 256 + 128 * 3 + 5, 128 * 256 + 1, 1531 * 50])
 def test_fused_mlp_matches_float32_reference(rows):
     """x += fc2(gelu(fc1(LN(x)))) in one kernel vs the float32 evaluation (GELU on the bf16-rounded pre-activation, as the
     bf16 pipeline and the kernel's table define it)."""
