@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Golden vectors for the TrainableViTExtractor inference path, produced by running the
+REFERENCE's own `_run_inference` (`vit_colmap/features/trainable_vit_extractor.py:139-267`) on CPU.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden_trainable.py
+
+* The module is imported with inert `sys.modules` entries for `cv2` / `torchvision` (absent in this image).  The two
+  `cv2` calls of `_run_inference` are I/O-side: `cvtColor` (channel flip) and `resize` of the frame that is fed to the
+  model; both get recording doubles that return arrays of the right shape, because
+* the model is replaced by a callable that returns the seeded head outputs of `cases_trainable.py` (no weights are
+  shipped and `torch.hub` is unreachable), and the transform by one that returns a zero tensor.  Everything from the
+  model's outputs on — sigmoid, max-pool NMS, threshold, top-k, sub-pixel offsets, the x4 and original-size scaling,
+  clamping, the 6-column keypoint rows and the (d + 1) * 127.5 quantiser — is the reference's code.
+* The object is built with `__new__` (the constructor would load the hub model).
+* A case whose candidate scores contain a tie is rejected (torch.topk leaves tie order unspecified).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from cases_trainable import CASES, make_head_outputs, map_hw  # noqa: E402
+
+REF = "/root/reference"
+
+
+def load_reference():
+    for name in ("cv2", "torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_BGR2RGB, cv2.INTER_LINEAR = 4, 1
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[..., ::-1])
+    cv2.resize = lambda img, wh, interpolation=None: np.zeros((wh[1], wh[0], img.shape[2]), img.dtype)
+    sys.path.insert(0, REF)
+    import importlib
+
+    return importlib.import_module("vit_colmap.features.trainable_vit_extractor").TrainableViTExtractor
+
+
+def main():
+    torch.set_num_threads(1)
+    cls = load_reference()
+    for case in CASES:
+        kp_map, d_map = make_head_outputs(case)
+        (h_new, w_new), (H, W) = map_hw(case)
+        ex = cls.__new__(cls)
+        ex.num_keypoints, ex.descriptor_dim = case["num_keypoints"], case["descriptor_dim"]
+        ex.score_threshold, ex.nms_radius = case["score_threshold"], case["nms_radius"]
+        ex.device, ex.patch_size = torch.device("cpu"), 14
+        seen = {}
+
+        def transform(img, seen=seen):
+            seen["hw"] = img.shape[:2]
+            return torch.zeros(3, img.shape[0], img.shape[1])
+
+        ex.transform = transform
+        ex.model = lambda x: {"keypoints": torch.from_numpy(kp_map)[None], "descriptors": torch.from_numpy(d_map)[None]}
+        h, w = case["orig_hw"]
+        kps, desc = ex._run_inference(np.zeros((h, w, 3), np.uint8))
+        assert seen["hw"] == (h_new, w_new), (seen, h_new, w_new)
+        if len(kps) and len(np.unique(kps[:, 4])) != len(kps):
+            raise SystemExit(f"{case['name']}: tie among selected scores; change the seed")
+        # also reject a tie at the cut: the candidate just below the last selected one must differ from it
+        path = os.path.join(HERE, f"trainable_{case['name']}.npz")
+        np.savez_compressed(path, keypoints=kps.astype(np.float32), descriptors=desc.astype(np.uint8))
+        print(f"{case['name']}: map {H}x{W} -> {kps.shape[0]} keypoints, {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""oracle/trainable_oracle.py against the golden vectors produced by the reference's own `_run_inference`
+(tests/golden/make_golden_trainable.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.dirname(HERE))
+from cases_trainable import CASES, make_head_outputs, map_hw  # noqa: E402
+from oracle import trainable_oracle as to  # noqa: E402
+
+
+def golden(case):
+    g = np.load(os.path.join(HERE, "golden", f"trainable_{case['name']}.npz"))
+    return g["keypoints"], g["descriptors"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_run_inference(case):
+    kp_map, d_map = make_head_outputs(case)
+    new_hw, _ = map_hw(case)
+    kps, du8 = to.run_inference_post(kp_map, d_map, case["orig_hw"], new_hw, case["num_keypoints"],
+                                     case["score_threshold"], case["nms_radius"])
+    gk, gd = golden(case)
+    assert kps.shape == gk.shape and du8.shape == gd.shape
+    if len(gk) == 0:
+        return
+    cols = [0, 1, 2, 3, 5]
+    assert np.array_equal(kps[:, cols].view(np.uint32), gk[:, cols].view(np.uint32))      # bit-exact
+    # the score column: torch's float32 sigmoid vs the correctly rounded one, <= 1 ulp
+    assert np.all(np.abs(kps[:, 4].view(np.int32).astype(np.int64) - gk[:, 4].view(np.int32).astype(np.int64)) <= 1)
+    assert np.array_equal(du8, gd)
+
+
+def test_nms_keeps_plateaus_and_pads_with_minus_infinity():
+    s = np.zeros((5, 6), np.float32)
+    s[2, 2] = s[2, 3] = 0.75            # a two-cell plateau: both kept (equality test), neighbours dropped
+    s[0, 0] = 0.5
+    keep = to.simple_nms(s, 1)
+    assert keep[2, 2] and keep[2, 3] and keep[0, 0] and not keep[1, 2] and not keep[2, 1]
+    assert keep[4, 5]                   # zero cell whose whole window is zero: equal to the max, kept by the reference too
+
+
+def test_ties_are_ordered_by_position():
+    kp = np.zeros((4, 4, 4), np.float32)
+    kp[0] = -5.0
+    kp[0, 3, 1] = kp[0, 0, 2] = 2.0     # equal scores far apart
+    pos, sc = to.select(kp, 2, 0.5, 1)
+    assert list(pos) == [2, 13] and sc[0] == sc[1]

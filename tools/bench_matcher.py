@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kind", default="vit")
     ap.add_argument("--pairs", default="exhaustive", help="exhaustive | sameb | samea | sorted_b")
+    ap.add_argument("--limit", type=int, default=0, help="keep only the first LIMIT pairs of the list")
     a = ap.parse_args()
     desc, counts = image_set(1, a.images, a.n, a.d, kind=a.kind)
     dd, dc = torch.from_numpy(desc).cuda(), torch.from_numpy(counts).cuda()
@@ -39,6 +40,8 @@ def main():
         src = (idx % 8) * chunk + idx // 8
         src = np.minimum(src, n - 1)
         pairs = torch.from_numpy(np.ascontiguousarray(pn[src])).cuda()
+    if a.limit:
+        pairs = pairs[: a.limit].contiguous()
     P = pairs.shape[0]
     prepared = prepare_descriptors(dd, dc)
     m = torch.empty((P, a.n, 2), dtype=torch.int32, device="cuda")
