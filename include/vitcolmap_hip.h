@@ -152,6 +152,30 @@ int vc_describe(const void* tokens, int token_dtype, int n_images, int H, int W,
 int vc_quantize_u8(const float* in, uint8_t* out, size_t n, vc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Keypoints + descriptors from dense head outputs — replaces the post-model part of
+ * TrainableViTExtractor._run_inference (reference vit_colmap/features/trainable_vit_extractor.py:170-267;
+ * _simple_nms :114-138).  Specification: oracle/trainable_oracle.py.  Batched over same-size images.
+ *   kp_map        [n_images][4][H][W] float32: score logit, dx, dy, orientation (model output "keypoints")
+ *   desc_map      float32 descriptor map (model output "descriptors", unit norm), element (image i, channel c,
+ *                 cell p = y W + x) at i desc_image_stride + c desc_channel_stride + p desc_pixel_stride, so both
+ *                 the reference's [D][H][W] (strides D H W, H W, 1) and a channels-last map (H W D, 1, D) are accepted
+ *   score = sigmoid(logit) (correctly rounded float32); candidate iff score equals the maximum of its
+ *   (2 nms_radius + 1)^2 window (-inf outside the map) and score > score_threshold; the kmax best by (score
+ *   descending, position ascending) are kept (trainable_vit_extractor.py:181-210).
+ *   out_keypoints [n_images][kmax][6] float32: x = clamp((((col + dx) + 0.5) 4) scale_x, 0, x_max), y likewise,
+ *                 1, orientation, score, 0  (:219-254; scale_x = float32(orig_w / resized_w), x_max = orig_w - 1)
+ *   out_desc      [n_images][kmax][D] uint8 = trunc(clip((d + 1) 127.5, 0, 255))  (:265-267)
+ *   out_count     [n_images] int32; rows >= count are zero (whole blocks for vc_prepare_descriptors)
+ *   workspace     vc_heatmap_workspace_bytes(n_images, H, W, kmax) bytes, 16-byte aligned.  kmax <= 65536.
+ */
+size_t vc_heatmap_workspace_bytes(int n_images, int H, int W, int kmax);
+int vc_heatmap_keypoints(const float* kp_map, const float* desc_map, long long desc_image_stride,
+                         long long desc_channel_stride, long long desc_pixel_stride, int n_images, int H, int W,
+                         int D, int nms_radius, float score_threshold, int kmax, float scale_x, float scale_y,
+                         float x_max, float y_max, void* workspace, float* out_keypoints, uint8_t* out_desc,
+                         int32_t* out_count, vc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Image preprocessing — replaces reference vit_extractor.py:117-132 (BGR->RGB, resize to
  * multiples of 14 with cv2.INTER_LINEAR, /255, ImageNet mean/std), batched.
  * ------------------------------------------------------------------------------------------ */

@@ -13,6 +13,11 @@ Run in the build container only (needs /root/reference):  python tests/golden/ma
   clamping, the 6-column keypoint rows and the (d + 1) * 127.5 quantiser — is the reference's code.
 * The object is built with `__new__` (the constructor would load the hub model).
 * A case whose candidate scores contain a tie is rejected (torch.topk leaves tie order unspecified).
+* `trainable_heads.npz`: the reference's `ViTFeatureModel.forward_from_backbone_features`
+  (`vit_colmap/model/vit_feature_model.py:231-293`) executed on an object built with `__new__` (its constructor loads
+  the hub backbone) that holds the seeded head modules of `vit_colmap_amd.model.ViTFeatureModel("dinov2_vits14", seed=5)`;
+  input = seeded backbone features (1, 384, 4, 5).  Pins upsampling, the bilinear resize to the 1/4-resolution target,
+  trunk, heads, tanh * pi and the L2 normalisation of this package's model against the reference's forward.
 """
 import os
 import sys
@@ -72,5 +77,29 @@ def main():
         print(f"{case['name']}: map {H}x{W} -> {kps.shape[0]} keypoints, {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def heads_case():
+    import importlib
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from vit_colmap_amd.model import ViTFeatureModel as Mine
+
+    ref_cls = importlib.import_module("vit_colmap.model.vit_feature_model").ViTFeatureModel
+    mine = Mine("dinov2_vits14", 128, seed=5).eval()
+    obj = ref_cls.__new__(ref_cls)
+    torch.nn.Module.__init__(obj)
+    obj.patch_size = 14
+    obj.upsampler, obj.trunk = mine.upsampler, mine.trunk
+    obj.keypoint_head, obj.descriptor_head = mine.keypoint_head, mine.descriptor_head
+    obj.eval()
+    feats = torch.from_numpy(np.random.RandomState(77).standard_normal((1, 384, 4, 5)).astype(np.float32))
+    with torch.inference_mode():
+        out = obj.forward_from_backbone_features(feats)            # target inferred: (4*14)//4 x (5*14)//4 = 14 x 17
+    path = os.path.join(HERE, "trainable_heads.npz")
+    np.savez_compressed(path, keypoints=out["keypoints"].numpy(), descriptors=out["descriptors"].numpy().astype(np.float16),
+                        descriptors_head=out["descriptors"].numpy()[:, :8])
+    print("heads:", tuple(out["keypoints"].shape), tuple(out["descriptors"].shape), f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     main()
+    heads_case()

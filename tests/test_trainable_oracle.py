@@ -50,3 +50,25 @@ def test_ties_are_ordered_by_position():
     kp[0, 3, 1] = kp[0, 0, 2] = 2.0     # equal scores far apart
     pos, sc = to.select(kp, 2, 0.5, 1)
     assert list(pos) == [2, 13] and sc[0] == sc[1]
+
+
+def test_model_heads_match_reference_forward():
+    """vit_colmap_amd.model.ViTFeatureModel.forward_from_backbone_features vs the reference's forward executed on the same
+    seeded head modules (tests/golden/trainable_heads.npz)."""
+    import torch
+
+    from vit_colmap_amd.model import ViTFeatureModel
+
+    g = np.load(os.path.join(HERE, "golden", "trainable_heads.npz"))
+    m = ViTFeatureModel("dinov2_vits14", 128, seed=5).eval()
+    feats = torch.from_numpy(np.random.RandomState(77).standard_normal((1, 384, 4, 5)).astype(np.float32))
+    with torch.inference_mode():
+        out = m.forward_from_backbone_features(feats)
+    assert tuple(out["keypoints"].shape) == (1, 4, 14, 17) and tuple(out["descriptors"].shape) == (1, 128, 14, 17)
+    np.testing.assert_allclose(out["keypoints"].numpy(), g["keypoints"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["descriptors"].numpy()[:, :8], g["descriptors_head"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["descriptors"].numpy(), g["descriptors"].astype(np.float32), atol=1e-3)
+    expected = {"upsampler.0.deconv.weight", "upsampler.1.conv.bias", "upsampler.1.bn.running_var", "trunk.0.weight", "trunk.1.running_mean",
+                "keypoint_head.0.weight", "keypoint_head.3.bias", "descriptor_head.1.weight", "descriptor_head.3.weight",
+                "backbone.cls_token", "backbone.blocks.0.attn.qkv.weight"}
+    assert expected <= set(m.state_dict())

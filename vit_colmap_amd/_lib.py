@@ -44,6 +44,10 @@ SIGNATURES = {
     "vc_describe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vc_quantize_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vc_heatmap_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vc_heatmap_keypoints": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int,
+                                     c_int, c_int, c_int, c_float, c_int, c_float, c_float, c_float, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "vc_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p]),
     "vc_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

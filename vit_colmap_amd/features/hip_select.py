@@ -113,3 +113,40 @@ def dense_to_sparse(tokens, H, W, original_wh, resized_wh, num_keypoints, method
     if want_f32:
         res["desc_f32"] = out[2]
     return res
+
+
+def heatmap_workspace_bytes(n_images: int, H: int, W: int, kmax: int) -> int:
+    return _lib.load().vc_heatmap_workspace_bytes(n_images, H, W, kmax)
+
+
+def heatmap_keypoints(kp_map: torch.Tensor, desc_map: torch.Tensor, num_keypoints: int, score_threshold: float,
+                      nms_radius: int, original_wh, resized_wh):
+    """Dense head outputs -> keypoints / descriptors (csrc/heatmap.hip; replaces the post-model part of the reference's
+    TrainableViTExtractor._run_inference, trainable_vit_extractor.py:170-267), batched.
+
+    kp_map (B, 4, H, W) float32 (logit, dx, dy, orientation); desc_map (B, D, H, W) float32 in any layout whose rows are
+    dense (contiguous or channels-last).  Returns dict: keypoints (B, K, 6) float32, desc_u8 (B, K, D) uint8 (rows beyond
+    count are zero), count (B,) int32."""
+    if not (kp_map.is_cuda and desc_map.is_cuda):
+        raise _lib.HipLibraryError("head outputs must live on the GPU (no CPU fallback)")
+    assert kp_map.dtype == torch.float32 and desc_map.dtype == torch.float32 and kp_map.dim() == 4 and kp_map.shape[1] == 4
+    kp_map = kp_map.contiguous()
+    B, _, H, W = kp_map.shape
+    D = desc_map.shape[1]
+    assert tuple(desc_map.shape) == (B, D, H, W), (desc_map.shape, kp_map.shape)
+    if desc_map.stride(2) != W * desc_map.stride(3):
+        desc_map = desc_map.contiguous()
+    lib = _lib.load()
+    dev = kp_map.device
+    K = int(num_keypoints)
+    ws = torch.empty(max(lib.vc_heatmap_workspace_bytes(B, H, W, K), 16), dtype=torch.uint8, device=dev)
+    kps = torch.empty((B, K, 6), dtype=torch.float32, device=dev)
+    du8 = torch.empty((B, K, D), dtype=torch.uint8, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    w_o, h_o = original_wh
+    w_n, h_n = resized_wh
+    _lib.check(lib.vc_heatmap_keypoints(_lib.ptr(kp_map), _lib.ptr(desc_map), desc_map.stride(0), desc_map.stride(1),
+                                        desc_map.stride(3), B, H, W, D, int(nms_radius), float(score_threshold), K,
+                                        float(w_o / w_n), float(h_o / h_n), float(w_o - 1), float(h_o - 1), _lib.ptr(ws),
+                                        _lib.ptr(kps), _lib.ptr(du8), _lib.ptr(cnt), _lib.stream_ptr()), "vc_heatmap_keypoints")
+    return {"keypoints": kps, "desc_u8": du8, "count": cnt}

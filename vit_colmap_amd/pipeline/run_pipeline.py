@@ -29,10 +29,16 @@ class Pipeline:
         if kind == "dummy":                                   # run_pipeline.py:321-323
             logger.info("Using Dummy extractor")
             return DummyExtractor(step=32)
-        if kind in ("colmap_sift", "trainable_vit"):          # :324-334 — third party / needs trained heads
+        if kind == "colmap_sift":                             # :323-325 — third-party C++ SIFT
             raise NotImplementedError(
                 f"extractor_type={kind!r} is outside the accelerated hot path (SURVEY.md §2); "
                 "use the reference implementation for it")
+        if kind == "trainable_vit":                           # :326-333
+            logger.info("Using Trainable ViT extractor")
+            from ..features.trainable_vit_extractor import TrainableViTExtractor
+
+            return TrainableViTExtractor(weights_path=self.config.extractor.vit_weights_path, num_keypoints=20480,
+                                         nms_radius=1, score_threshold=0.4)
         logger.info("Using ViT extractor")                     # :335-339 (any other value -> ViT)
         from ..features.vit_extractor import ViTExtractor
 
