@@ -153,3 +153,24 @@ def test_extractor_end_to_end_and_database(tmp_path):
     cam = con.execute("SELECT model, params FROM cameras").fetchone()
     assert np.allclose(np.frombuffer(cam[1], np.float64), [160, 80, 60, 0.0])
     con.close()
+
+
+def test_bf16_heads_track_the_float32_heads():
+    """precision="bf16" runs the convolutional heads in bf16 (MIOpen) after folding BatchNorm in float32; the maps stay
+    close to the float32 evaluation of the same weights (8-bit mantissa through 7 convolutions)."""
+    from vit_colmap_amd.features.trainable_vit_extractor import TrainableViTExtractor
+
+    frames = torch.from_numpy(np.random.RandomState(2).randint(0, 255, (2, 112, 154, 3)).astype(np.uint8)).cuda()
+    maps = {}
+    for prec in ("fp32", "bf16"):
+        ex = TrainableViTExtractor(model_name="dinov2_vits14", num_keypoints=100, device="cuda", precision=prec, seed=4)
+        # identical backbone features for both: the comparison is about the heads
+        if prec == "fp32":
+            tokens = torch.randn(2, 8 * 11, 384, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+        feats = ex.model.tokens_to_grid(tokens.to(ex.dtype), 8, 11)
+        with torch.inference_mode():
+            out = ex.model.forward_from_backbone_features(feats, target_size=(28, 38))
+        maps[prec] = (out["keypoints"].float(), out["descriptors"].float())
+    for a, b in zip(maps["fp32"], maps["bf16"]):
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 5e-2, rel

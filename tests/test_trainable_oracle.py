@@ -72,3 +72,27 @@ def test_model_heads_match_reference_forward():
                 "keypoint_head.0.weight", "keypoint_head.3.bias", "descriptor_head.1.weight", "descriptor_head.3.weight",
                 "backbone.cls_token", "backbone.blocks.0.attn.qkv.weight"}
     assert expected <= set(m.state_dict())
+
+
+def test_fold_batchnorm_is_exact_up_to_rounding():
+    import torch
+
+    from vit_colmap_amd.model import ViTFeatureModel
+
+    m = ViTFeatureModel("dinov2_vits14", 64, seed=9).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():                      # non-trivial statistics
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.3)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.weight.copy_(1 + 0.2 * torch.randn(mod.num_features, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.num_features, generator=g))
+    feats = torch.randn(1, 384, 3, 4, generator=g)
+    with torch.inference_mode():
+        a = m.forward_from_backbone_features(feats)
+        m.fold_batchnorm()
+        b = m.forward_from_backbone_features(feats)
+    assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in m.modules())
+    for k in ("keypoints", "descriptors"):
+        np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-5)

@@ -54,7 +54,7 @@ class TrainableViTExtractor(BaseExtractor):
         score_threshold: float = 0.0,
         nms_radius: int = 4,
         *,
-        precision: str = "bf16",     # backbone precision; the heads run in float32 like the reference's
+        precision: str = "bf16",     # "bf16": backbone and convolutional heads on the matrix cores; "fp32": the reference's precision
         batch_size: int = 8,
         seed: int = 0,
     ):
@@ -80,8 +80,9 @@ class TrainableViTExtractor(BaseExtractor):
         if self.device.type == "cuda" and self.dtype == torch.bfloat16:
             self.model.to(self.device)
             self.model.backbone.prepare_hip()          # hand-written GEMM operands (ViT-S only; no-op otherwise)
+        self.model.fold_batchnorm()                    # float32, before any cast
         self.model.to(self.device)
-        self.model.backbone.to(dtype=self.dtype)
+        self.model.to(dtype=self.dtype)                # heads too: MIOpen bf16 convolutions; their outputs are read back as float32
         if self.device.type == "cuda":
             self.model.upsampler.to(memory_format=torch.channels_last)
             self.model.trunk.to(memory_format=torch.channels_last)

@@ -108,6 +108,24 @@ class ViTFeatureModel(nn.Module):
         descriptors = F.normalize(descriptors, p=2, dim=1, eps=1e-8)
         return {"keypoints": keypoints, "descriptors": descriptors, "features": trunk}
 
+    @torch.no_grad()
+    def fold_batchnorm(self):
+        """Inference only: every eval-mode BatchNorm follows a convolution, so its affine map goes into that convolution's
+        weights and bias (w' = w g / sqrt(var + eps), b' = (b - mean) g / sqrt(var + eps) + beta; exact in real arithmetic,
+        done in float32) and the BatchNorm becomes the identity — five passes over the largest activations less."""
+        def fold(conv, bn):
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            conv.weight.mul_(scale[:, None, None, None])
+            conv.bias.copy_((conv.bias - bn.running_mean) * scale + bn.bias)
+
+        for blk in self.upsampler:
+            fold(blk.conv, blk.bn)
+            blk.bn = nn.Identity()
+        for seq in (self.trunk, self.keypoint_head, self.descriptor_head):
+            fold(seq[0], seq[1])
+            seq[1] = nn.Identity()
+        return self
+
     # ------------------------------------------------------------------------------------------
     def load_reference_state_dict(self, state_dict) -> None:
         """A state dict saved from the reference's ViTFeatureModel (hub backbone names under `backbone.`)."""
