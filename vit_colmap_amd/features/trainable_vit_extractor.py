@@ -10,6 +10,11 @@ What runs where
            keypoints, descriptor gather + quantiser (csrc/heatmap.hip, `vc_heatmap_keypoints`); no CPU fallback
   PyTorch  the convolutional upsampler / trunk / heads (MIOpen), channels-last on the backbone's token grid
 
+Throughput (1x MI355X, 640x480, batches of 8, `tools/bench_heatmap.py`): 830 images/s with the ViT-S backbone, 670 with ViT-B
+(bf16; 307 / 274 with float32 heads); the convolutional heads are ~85 % of that time, the post-model HIP path 0.3 ms per 50
+images.  The first batch of a new image size runs MIOpen's solver search for the seven convolution shapes (~30 s, cached by
+MIOpen per user afterwards); `MIOPEN_FIND_MODE=2` skips the search at 5x lower head throughput.
+
 Differences from the reference, deliberate: images are processed in batches of equal size; without `weights_path` the
 reference downloads the pretrained backbone through torch.hub and leaves the heads at torch's default initialisation —
 offline, backbone AND heads are seeded random and a warning is printed; checkpoints are read with
