@@ -99,6 +99,11 @@ def test_preprocess_bit_exact_resize_and_layouts():
         np.testing.assert_allclose(nchw[k].cpu().numpy(), x, rtol=1e-6, atol=1e-6)
         assert np.array_equal(patches[k].cpu().numpy(), po.patchify(nchw[k].cpu().numpy()))
     assert torch.equal(p16, patches.to(torch.bfloat16))                           # RN-even cast
+    ppad = hp.preprocess(d, torch.bfloat16, "patches_pad")                        # wave-per-patch kernel of the ViT-S path
+    assert tuple(ppad.shape) == (3, 34 * 45, 640)
+    assert torch.equal(ppad[..., :588], p16) and not bool(ppad[..., 588:].any())
+    odd = torch.from_numpy(np.ascontiguousarray(imgs[:2, :101, :211])).cuda()     # 7 x 15 patches: partial last workgroup
+    assert torch.equal(hp.preprocess(odd, torch.bfloat16, "patches_pad")[..., :588], hp.preprocess(odd, torch.bfloat16, "patches"))
     same = hp.preprocess(torch.from_numpy(np.ascontiguousarray(imgs[:, :476, :630])).cuda(), torch.float32, "nchw",
                          want_resized=True)[1]
     assert np.array_equal(same.cpu().numpy(), imgs[:, :476, :630])                # no resize when already aligned

@@ -101,6 +101,47 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
   }
 }
 
+// The ViT-S path's layout (bf16 patches padded to 640 elements), one wave per patch: the 14 + 14 interpolation coefficients
+// of the patch are computed once (float64 source coordinate as in the generic kernel), every lane produces ten of the
+// 588 elements into a 1280-byte LDS image of the patch row, and the row leaves as 80 coalesced 16-byte stores (the
+// generic kernel's thread-per-pixel mapping writes 2-byte elements in 28-byte runs).  Same arithmetic, same bits.
+__global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* __restrict__ img, int h, int w, int oh, int ow,
+                                                                 double scale_x, double scale_y, uint16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint16_t row_l[4][kPatchPad];
+  __shared__ Coef coef_l[4][2][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, hp = oh / kPatch, wp = ow / kPatch;
+  const int patch = blockIdx.x * 4 + wave;
+  const bool live = patch < hp * wp;
+  const int pc = live ? patch : hp * wp - 1;
+  const int py = pc / wp, pxx = pc - py * wp;
+  if (lane < 14) coef_l[wave][0][lane] = linear_coef(pxx * kPatch + lane, w, scale_x);
+  else if (lane >= 16 && lane < 30) coef_l[wave][1][lane - 16] = linear_coef(py * kPatch + lane - 16, h, scale_y);
+  __syncthreads();
+  const uint8_t* src = img + (size_t)n * h * w * 3;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  for (int e = lane; e < kPatchPad; e += 64) {
+    uint16_t v16 = 0;                                   // elements 588 .. 639: the K padding
+    if (e < 3 * kPatch * kPatch) {
+      const int c = e / (kPatch * kPatch), rem = e - c * (kPatch * kPatch), dy = rem / kPatch, dx = rem - dy * kPatch;
+      const Coef cx = coef_l[wave][0][dx], cy = coef_l[wave][1][dy];
+      const int cc = 2 - c;                             // channel c of RGB is channel 2-c of BGR
+      const int r0 = src[((size_t)cy.s0 * w + cx.s0) * 3 + cc] * cx.a0 + src[((size_t)cy.s0 * w + cx.s1) * 3 + cc] * cx.a1;
+      const int r1 = src[((size_t)cy.s1 * w + cx.s0) * 3 + cc] * cx.a0 + src[((size_t)cy.s1 * w + cx.s1) * 3 + cc] * cx.a1;
+      const int px = (((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      const float t = (float)px / 255.0f;
+      v16 = f32_to_bf16((t - mean[c]) / stdv[c]);
+    }
+    row_l[wave][e] = v16;
+  }
+  __syncthreads();
+  if (!live) return;
+  uint8_t* dst = (uint8_t*)(out + ((size_t)n * hp * wp + patch) * kPatchPad);
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  for (int q = lane; q < kPatchPad * 2 / 16; q += 64) *(v4u*)(dst + q * 16) = *(const v4u*)((const uint8_t*)row_l[wave] + q * 16);
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,6 +153,12 @@ int vc_preprocess_u8(const uint8_t* images_bgr, int n_images, int h, int w, int 
   if (layout != VC_LAYOUT_NCHW && layout != VC_LAYOUT_PATCHES && layout != VC_LAYOUT_PATCHES_PAD) return VC_ERR_INVALID_ARG;
   if (layout != VC_LAYOUT_NCHW && (out_h % kPatch != 0 || out_w % kPatch != 0)) return VC_ERR_INVALID_ARG;
   if (n_images == 0) return VC_OK;
+  if (layout == VC_LAYOUT_PATCHES_PAD && out_dtype == VC_DTYPE_BF16 && !resized_bgr_or_null && ((uintptr_t)out) % 16 == 0) {
+    const int n_patches = (out_h / kPatch) * (out_w / kPatch);
+    hipLaunchKernelGGL(preprocess_patches_kernel, dim3((n_patches + 3) / 4, n_images), dim3(256), 0, (hipStream_t)stream, images_bgr,
+                       h, w, out_h, out_w, (double)w / (double)out_w, (double)h / (double)out_h, (uint16_t*)out);
+    return vc::check_launch();
+  }
   const dim3 grid((out_h * out_w + 255) / 256, n_images);
   if (out_dtype == VC_DTYPE_F32)
     hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, images_bgr, h, w, out_h,
