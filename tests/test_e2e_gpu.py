@@ -104,6 +104,17 @@ def test_preprocess_bit_exact_resize_and_layouts():
     assert torch.equal(ppad[..., :588], p16) and not bool(ppad[..., 588:].any())
     odd = torch.from_numpy(np.ascontiguousarray(imgs[:2, :101, :211])).cuda()     # 7 x 15 patches: partial last workgroup
     assert torch.equal(hp.preprocess(odd, torch.bfloat16, "patches_pad")[..., :588], hp.preprocess(odd, torch.bfloat16, "patches"))
+    # strong down-scaling through the C ABI (source window of a patch larger than its LDS staging: taps from global memory)
+    # and an up-scaling: padded bf16 patches == unpadded bf16 patches
+    from vit_colmap_amd import _lib
+    lib = _lib.load()
+    for (oh, ow) in ((56, 84), (140, 98), (476, 630), (966, 1274)):
+        a = torch.empty((3, (oh // 14) * (ow // 14), 588), dtype=torch.bfloat16, device="cuda")
+        b = torch.full((3, (oh // 14) * (ow // 14), 640), 7.0, dtype=torch.bfloat16, device="cuda")
+        for lay, o in ((1, a), (2, b)):
+            _lib.check(lib.vc_preprocess_u8(_lib.ptr(d), 3, 480, 640, oh, ow, 1, lay, _lib.ptr(o), None, _lib.stream_ptr()), "vc_preprocess_u8")
+        torch.cuda.synchronize()
+        assert torch.equal(b[..., :588], a) and not bool(b[..., 588:].any()), (oh, ow)
     same = hp.preprocess(torch.from_numpy(np.ascontiguousarray(imgs[:, :476, :630])).cuda(), torch.float32, "nchw",
                          want_resized=True)[1]
     assert np.array_equal(same.cpu().numpy(), imgs[:, :476, :630])                # no resize when already aligned

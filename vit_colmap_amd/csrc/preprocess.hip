@@ -105,33 +105,96 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 // of the patch are computed once (float64 source coordinate as in the generic kernel), every lane produces ten of the
 // 588 elements into a 1280-byte LDS image of the patch row, and the row leaves as 80 coalesced 16-byte stores (the
 // generic kernel's thread-per-pixel mapping writes 2-byte elements in 28-byte runs).  Same arithmetic, same bits.
-__global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* __restrict__ img, int h, int w, int oh, int ow,
-                                                                 double scale_x, double scale_y, uint16_t* __restrict__ out) {
+// The patch's source window (about 16 rows x 16 pixels x 3 bytes) is staged in LDS with dword loads and the taps read
+// from there; s0 / s1 of the coefficient tables then hold byte offsets into the window.
+constexpr int kWinRowBytes = 96, kWinRows = 24;
+__global__ __launch_bounds__(256) void preprocess_patches_kernel(const uint8_t* __restrict__ img, int n_images, int h, int w, int oh,
+                                                                 int ow, double scale_x, double scale_y,
+                                                                 uint16_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint16_t row_l[4][kPatchPad];
+  __shared__ __attribute__((aligned(16))) uint8_t win_l[4][kWinRows * kWinRowBytes];
   __shared__ Coef coef_l[4][2][16];
+  // normalised value of every (channel, 8-bit pixel) pair, by the generic kernel's expressions (768 entries per workgroup
+  // instead of two IEEE float divisions per element)
+  __shared__ uint16_t norm_l[3][256];
+  {
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int i = threadIdx.x; i < 768; i += 256) {
+      const int c = i >> 8;
+      const float t = (float)(i & 255) / 255.0f;
+      norm_l[c][i & 255] = f32_to_bf16((t - mean[c]) / stdv[c]);
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.y, hp = oh / kPatch, wp = ow / kPatch;
   const int patch = blockIdx.x * 4 + wave;
   const bool live = patch < hp * wp;
   const int pc = live ? patch : hp * wp - 1;
   const int py = pc / wp, pxx = pc - py * wp;
-  if (lane < 14) coef_l[wave][0][lane] = linear_coef(pxx * kPatch + lane, w, scale_x);
-  else if (lane >= 16 && lane < 30) coef_l[wave][1][lane - 16] = linear_coef(py * kPatch + lane - 16, h, scale_y);
+  // source window of the patch: the coefficients are monotonic in the output coordinate, so the first / last of the 14
+  // give its bounds (every lane evaluates these four: wave-uniform values without a round trip through LDS)
+  const int xs0 = linear_coef(pxx * kPatch, w, scale_x).s0, xs1 = linear_coef(pxx * kPatch + 13, w, scale_x).s1;
+  const int ys0 = linear_coef(py * kPatch, h, scale_y).s0, ys1 = linear_coef(py * kPatch + 13, h, scale_y).s1;
+  const int nxb = (xs1 - xs0 + 1) * 3, ny = ys1 - ys0 + 1;
+  const bool use_win = nxb + 6 <= kWinRowBytes && ny <= kWinRows;       // wave-uniform
+  const size_t img_bytes = (size_t)h * w * 3, all_bytes = img_bytes * n_images;
+  const size_t img_off = (size_t)n * img_bytes;
+  const uint8_t* src = img + img_off;
+  const uint32_t off3 = (uint32_t)(img_off & 3);
+  // coefficient tables; with a window, s0 / s1 become byte offsets into it (x: 3 (s - xs0); y: row start + misalignment)
+  if (lane < 14) {
+    Coef c = linear_coef(pxx * kPatch + lane, w, scale_x);
+    if (use_win) { c.s0 = (c.s0 - xs0) * 3; c.s1 = (c.s1 - xs0) * 3; }
+    coef_l[wave][0][lane] = c;
+  } else if (lane >= 16 && lane < 30) {
+    Coef c = linear_coef(py * kPatch + lane - 16, h, scale_y);
+    if (use_win) {
+      const uint32_t a0 = (off3 + ((uint32_t)c.s0 * (uint32_t)w + (uint32_t)xs0) * 3u) & 3u;   // mod 4: 32-bit wrap is harmless
+      const uint32_t a1 = (off3 + ((uint32_t)c.s1 * (uint32_t)w + (uint32_t)xs0) * 3u) & 3u;
+      c.s0 = (c.s0 - ys0) * kWinRowBytes + (int)a0;
+      c.s1 = (c.s1 - ys0) * kWinRowBytes + (int)a1;
+    }
+    coef_l[wave][1][lane - 16] = c;
+  }
+  uint8_t* const win = win_l[wave];
+  if (use_win) {
+    // the window, ~4 dword loads per lane (the generic kernel issues 12 byte loads per output pixel)
+    const int dw_row = (nxb + 6) >> 2;                                  // dwords per row incl. worst-case misalignment
+    for (int idx = lane; idx < ny * dw_row; idx += 64) {
+      const int row = idx / dw_row, j = idx - row * dw_row;
+      const size_t rb = img_off + ((size_t)(ys0 + row) * w + xs0) * 3;  // byte offset of the row's first tap in the batch
+      const size_t a = (rb & ~(size_t)3) + (size_t)j * 4;               // img is 4-byte aligned (host check)
+      uint32_t v;
+      if (a + 4 <= all_bytes) {
+        v = *(const uint32_t*)(img + a);
+      } else {                                                          // last bytes of the batch
+        v = 0;
+        for (int k = 0; k < 4; ++k)
+          if (a + k < all_bytes) v |= (uint32_t)img[a + k] << (8 * k);
+      }
+      *(uint32_t*)(win + row * kWinRowBytes + j * 4) = v;
+    }
+  }
   __syncthreads();
-  const uint8_t* src = img + (size_t)n * h * w * 3;
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float stdv[3] = {0.229f, 0.224f, 0.225f};
   for (int e = lane; e < kPatchPad; e += 64) {
     uint16_t v16 = 0;                                   // elements 588 .. 639: the K padding
     if (e < 3 * kPatch * kPatch) {
       const int c = e / (kPatch * kPatch), rem = e - c * (kPatch * kPatch), dy = rem / kPatch, dx = rem - dy * kPatch;
       const Coef cx = coef_l[wave][0][dx], cy = coef_l[wave][1][dy];
       const int cc = 2 - c;                             // channel c of RGB is channel 2-c of BGR
-      const int r0 = src[((size_t)cy.s0 * w + cx.s0) * 3 + cc] * cx.a0 + src[((size_t)cy.s0 * w + cx.s1) * 3 + cc] * cx.a1;
-      const int r1 = src[((size_t)cy.s1 * w + cx.s0) * 3 + cc] * cx.a0 + src[((size_t)cy.s1 * w + cx.s1) * 3 + cc] * cx.a1;
+      int p00, p01, p10, p11;
+      if (use_win) {
+        p00 = win[cy.s0 + cx.s0 + cc]; p01 = win[cy.s0 + cx.s1 + cc];
+        p10 = win[cy.s1 + cx.s0 + cc]; p11 = win[cy.s1 + cx.s1 + cc];
+      } else {                                          // strong down-scaling: taps from global memory
+        p00 = src[((size_t)cy.s0 * w + cx.s0) * 3 + cc]; p01 = src[((size_t)cy.s0 * w + cx.s1) * 3 + cc];
+        p10 = src[((size_t)cy.s1 * w + cx.s0) * 3 + cc]; p11 = src[((size_t)cy.s1 * w + cx.s1) * 3 + cc];
+      }
+      const int r0 = p00 * cx.a0 + p01 * cx.a1;
+      const int r1 = p10 * cx.a0 + p11 * cx.a1;
       const int px = (((cy.a0 * (r0 >> 4)) >> 16) + ((cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
-      const float t = (float)px / 255.0f;
-      v16 = f32_to_bf16((t - mean[c]) / stdv[c]);
+      v16 = norm_l[c][px];
     }
     row_l[wave][e] = v16;
   }
@@ -153,10 +216,11 @@ int vc_preprocess_u8(const uint8_t* images_bgr, int n_images, int h, int w, int 
   if (layout != VC_LAYOUT_NCHW && layout != VC_LAYOUT_PATCHES && layout != VC_LAYOUT_PATCHES_PAD) return VC_ERR_INVALID_ARG;
   if (layout != VC_LAYOUT_NCHW && (out_h % kPatch != 0 || out_w % kPatch != 0)) return VC_ERR_INVALID_ARG;
   if (n_images == 0) return VC_OK;
-  if (layout == VC_LAYOUT_PATCHES_PAD && out_dtype == VC_DTYPE_BF16 && !resized_bgr_or_null && ((uintptr_t)out) % 16 == 0) {
+  if (layout == VC_LAYOUT_PATCHES_PAD && out_dtype == VC_DTYPE_BF16 && !resized_bgr_or_null && ((uintptr_t)out) % 16 == 0 &&
+      ((uintptr_t)images_bgr) % 4 == 0) {
     const int n_patches = (out_h / kPatch) * (out_w / kPatch);
     hipLaunchKernelGGL(preprocess_patches_kernel, dim3((n_patches + 3) / 4, n_images), dim3(256), 0, (hipStream_t)stream, images_bgr,
-                       h, w, out_h, out_w, (double)w / (double)out_w, (double)h / (double)out_h, (uint16_t*)out);
+                       n_images, h, w, out_h, out_w, (double)w / (double)out_w, (double)h / (double)out_h, (uint16_t*)out);
     return vc::check_launch();
   }
   const dim3 grid((out_h * out_w + 255) / 256, n_images);
