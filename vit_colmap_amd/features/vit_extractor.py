@@ -8,7 +8,8 @@ What runs where
   HIP      preprocessing (resize / normalise / patchify), structure tensor, score map,
            binning + top-k + NMS, descriptor gather / projection / normalise / quantise
            — csrc/*.hip through the C ABI; there is no CPU fallback for any of it
-  PyTorch  the DINOv2 GEMMs and attention in bf16 (vit/dinov2.py)
+  HIP      the whole DINOv2 ViT-S forward in bf16 (csrc/gemm.hip, csrc/attention.hip, driven by vit/dinov2.py)
+  PyTorch  the GEMMs of the wider backbones (ViT-B/L/g: hipBLASLt) around the same HIP attention / LayerNorm kernels
 
 Differences from the reference, all deliberate:
   * images are processed in batches of equal size instead of one at a time;

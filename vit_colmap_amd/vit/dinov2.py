@@ -279,7 +279,7 @@ class DinoV2(nn.Module):
 
     def _blocks_hip(self, x):
         """ViT-S bf16 path on the hand-written GEMMs: LayerNorm lives in the x load of qkv / fc1, GELU and
-        both residual adds in GEMM epilogues; per block 5 kernels and no standalone elementwise pass."""
+        both residual adds in GEMM epilogues; per block 4 kernels (the MLP is one) and no standalone elementwise pass."""
         from . import hip_ops as ops
 
         for blk, hw in zip(self.blocks, self._hip):
