@@ -620,6 +620,10 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
     const uint8_t* st = lds + slot * XStage + lane * 16;
     {
       // the bias is the accumulator's initial value: register 4g + j <- bias[32 nb + 8g + 4h + j]
+#ifdef VC_XS_NOBIAS
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#else
       const float* bl = bias_l + nb * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -627,6 +631,7 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[4 * g + j] = bv[j];
       }
+#endif
     }
     {
       // W fragments are read XRD k-steps ahead of the MFMA that consumes them (LDS latency ~ 4 MFMAs);
