@@ -119,12 +119,21 @@ void run(const uint8_t* w, size_t w_bytes, uint32_t* out, int cus) {
          bytes_cu * cus / (ms * 1e-3) / 1e12, sg[0], sg[1], sg[2]);
 }
 
-int main() {
+int main(int argc, char**) {
   const size_t w_bytes = 2304 * 1024;
   uint8_t* w; uint32_t* out;
   hipMalloc(&w, w_bytes); hipMemset(w, 1, w_bytes);
   hipMalloc(&out, 256 * 512 * 4 + 256 * 8 * 4 * 4);
+  const bool wide = argc > 1;                           // any argument: the 48 KiB-stage variants only
   for (int cus : {256, 64}) {
+    if (wide) {
+      if (cus != 256) continue;
+      run<2, 3, 24, true, 1, 8>(w, w_bytes, out, cus);    // reference: 24 KiB stages
+      run<1, 6, 48, true, 1, 8>(w, w_bytes, out, cus);    // 48 KiB stages (two feature blocks per barrier), one in flight
+      run<2, 6, 48, true, 1, 8>(w, w_bytes, out, cus);    // ... two in flight (144 KiB of ring)
+      run<1, 6, 48, true, 2, 8>(w, w_bytes, out, cus);    // ... two accumulators
+      continue;
+    }
     run<1, 3, 0, true>(w, w_bytes, out, cus);
     run<2, 3, 0, true>(w, w_bytes, out, cus);
     run<4, 3, 0, true>(w, w_bytes, out, cus);
