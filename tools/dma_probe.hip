@@ -13,6 +13,7 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 // MF: 0 = no MFMA; 1 = one v_mfma_f32_32x32x16_bf16 per fragment read, all into ONE accumulator (xs_kernel's chain);
+// 4 = as 1 with the MFMA phases of waves 0-3 and 4-7 (the two waves of every SIMD) separated by a second barrier;
 // 2 = alternating between two accumulators; 3 = one accumulator, 24 distinct B operands; RD = fragments read ahead of the MFMA that consumes them
 template <int DEPTH, int PIECES, int READS, bool BARRIER, int MF = 0, int RD = 8>
 __global__ __launch_bounds__(512, 1) void k(const uint8_t* __restrict__ w, size_t w_bytes, int stages, uint32_t* out) {
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(512, 1) void k(const uint8_t* __restrict__ w, size_
     issue();                                            // refills the slot freed in the previous iteration
     ST(1)
     const uint8_t* st = lds + slot * StageBytes + lane * 16;
+    if (MF == 4 && wave >= 4) asm volatile("s_barrier" ::: "memory");   // late half: MFMA phase after the early half's
     if (MF == 0) {
 #pragma unroll
       for (int q = 0; q < READS; ++q) {
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(512, 1) void k(const uint8_t* __restrict__ w, size_
       }
     }
     if (MF) asm volatile("s_nop 0" :: "v"(acc0), "v"(acc1));
+    if (MF == 4 && wave < 4) asm volatile("s_barrier" ::: "memory");    // early half: done, release the late half
     ST(2)
     slot = slot + 1 == NS ? 0 : slot + 1;
   }
@@ -132,6 +135,8 @@ int main(int argc, char**) {
       run<1, 6, 48, true, 1, 8>(w, w_bytes, out, cus);    // 48 KiB stages (two feature blocks per barrier), one in flight
       run<2, 6, 48, true, 1, 8>(w, w_bytes, out, cus);    // ... two in flight (144 KiB of ring)
       run<1, 6, 48, true, 2, 8>(w, w_bytes, out, cus);    // ... two accumulators
+      run<2, 3, 24, true, 4, 8>(w, w_bytes, out, cus);    // 24 KiB stages, the two waves of a SIMD strictly one after the other
+      run<2, 3, 24, true, 4, 12>(w, w_bytes, out, cus);
       continue;
     }
     run<1, 3, 0, true>(w, w_bytes, out, cus);
