@@ -206,6 +206,12 @@ int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const voi
                           const void* beta, float eps, int rows, int C, void* sum_out_or_null,
                           void* y_out, vc_stream_t stream);
 
+/* Plain LayerNorm over rows that come in groups of group_rows (one image's tokens), dropping the FIRST row of every group
+ * (the class token, which nothing downstream reads: reference vit_extractor.py:140-142 takes x_norm_patchtokens):
+ * x [n_groups][group_rows][C] -> y [n_groups][group_rows - 1][C], dense.  Same arithmetic as vc_add_layernorm_bf16. */
+int vc_layernorm_drop_first_bf16(const void* x, const void* gamma, const void* beta, float eps, int n_groups,
+                                 int group_rows, int C, void* y_out, vc_stream_t stream);
+
 /*
  * Multi-head self-attention forward, head_dim 64 (DINOv2 ViT-S/B/L): softmax(Q K^T / 8) V.
  * qkv [batch][n_tokens][3][n_heads][64] bfloat16 (the fused qkv projection's output as it is),

@@ -272,3 +272,19 @@ def test_fused_mlp_matches_float32_reference(rows):
     err = (out - ref).abs()
     assert float((out - ref).norm() / ref.norm()) < 8e-3, float((out - ref).norm() / ref.norm())
     assert bool((err <= ref.abs() * 2 ** -6 + 0.12).all()), (float(err.max()), int((err > ref.abs() * 2 ** -6 + 0.12).sum()))
+
+
+def test_layernorm_drop_first_equals_layernorm_of_the_remaining_rows():
+    """vc_layernorm_drop_first_bf16: the final norm of the ViT-S path skips the class-token row of every image and writes the
+    patch tokens densely — bit-identical to vc_add_layernorm_bf16 on all rows followed by the slice."""
+    from vit_colmap_amd.vit.hip_ops import add_layernorm, layernorm_drop_first
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (B, N, C) in ((3, 1531, 384), (1, 2, 384), (5, 17, 768)):
+        x = (torch.randn(B, N, C, device="cuda", generator=g) * 2 + 0.5).to(torch.bfloat16)
+        w = (1 + 0.1 * torch.randn(C, device="cuda", generator=g)).to(torch.bfloat16)
+        b = (0.1 * torch.randn(C, device="cuda", generator=g)).to(torch.bfloat16)
+        _, full = add_layernorm(x, None, w, b, 1e-6)
+        y = layernorm_drop_first(x, w, b, 1e-6)
+        assert tuple(y.shape) == (B, N - 1, C)
+        assert torch.equal(y.view(torch.int16), full[:, 1:].contiguous().view(torch.int16))

@@ -50,6 +50,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "vc_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "vc_layernorm_drop_first_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vc_linear_xs_weight_bytes": (c_size_t, [c_int, c_int]),

@@ -39,12 +39,20 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ gamma,
                                                             const bf16_t* __restrict__ beta, float eps,
                                                             int rows, int C, bf16_t* __restrict__ sum_out,
-                                                            bf16_t* __restrict__ y_out) {
+                                                            bf16_t* __restrict__ y_out, int drop_group) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nchunk = C >> 3;
   const size_t base = (size_t)row * C;
+  // drop_group > 0: rows come in groups of drop_group (one image's tokens); the first row of every group (the class
+  // token) is not needed and y is written densely without it: y row = row - group - 1
+  size_t ybase = base;
+  if (drop_group > 0) {
+    const int grp = row / drop_group;
+    if (row - grp * drop_group == 0) return;
+    ybase = (size_t)(row - grp - 1) * C;
+  }
   float v[kMaxChunksPerLane][8];
   float s = 0.f;
 #pragma unroll
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const bf16_t* __rest
       Vec8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o.e[i] = f2bf((v[k][i] - mean) * rstd * bf2f(g.e[i]) + bf2f(bb.e[i]));
-      *(Vec8*)(y_out + base + ch * 8) = o;
+      *(Vec8*)(y_out + ybase + ch * 8) = o;
     }
   }
 }
@@ -98,8 +106,22 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const bf16_t* __rest
 
 extern "C" {
 
+static int add_layernorm_launch(const void* x, const void* residual_or_null, const void* gamma, const void* beta, float eps,
+                                int rows, int C, void* sum_out_or_null, void* y_out, int drop_group, vc_stream_t stream);
+
 int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const void* gamma, const void* beta,
                           float eps, int rows, int C, void* sum_out_or_null, void* y_out, vc_stream_t stream) {
+  return add_layernorm_launch(x, residual_or_null, gamma, beta, eps, rows, C, sum_out_or_null, y_out, 0, stream);
+}
+
+int vc_layernorm_drop_first_bf16(const void* x, const void* gamma, const void* beta, float eps, int n_groups, int group_rows,
+                                 int C, void* y_out, vc_stream_t stream) {
+  if (n_groups < 0 || group_rows < 2) return VC_ERR_INVALID_ARG;
+  return add_layernorm_launch(x, nullptr, gamma, beta, eps, n_groups * group_rows, C, nullptr, y_out, group_rows, stream);
+}
+
+static int add_layernorm_launch(const void* x, const void* residual_or_null, const void* gamma, const void* beta, float eps,
+                                int rows, int C, void* sum_out_or_null, void* y_out, int drop_group, vc_stream_t stream) {
   if (!x || !gamma || !beta || !y_out || rows < 0 || C <= 0) return VC_ERR_INVALID_ARG;
   if (C % 8 != 0 || C > 64 * kMaxChunksPerLane * 8) return VC_ERR_UNSUPPORTED;
   if ((((uintptr_t)x) | ((uintptr_t)y_out) | ((uintptr_t)gamma) | ((uintptr_t)beta) |
@@ -112,11 +134,11 @@ int vc_add_layernorm_bf16(const void* x, const void* residual_or_null, const voi
                *pb = (const bf16_t*)beta;
   bf16_t *ps = (bf16_t*)sum_out_or_null, *py = (bf16_t*)y_out;
   if (!pr)
-    hipLaunchKernelGGL((add_layernorm_kernel<false, false>), grid, block, 0, s, px, pr, pg, pb, eps, rows, C, ps, py);
+    hipLaunchKernelGGL((add_layernorm_kernel<false, false>), grid, block, 0, s, px, pr, pg, pb, eps, rows, C, ps, py, drop_group);
   else if (ps)
-    hipLaunchKernelGGL((add_layernorm_kernel<true, true>), grid, block, 0, s, px, pr, pg, pb, eps, rows, C, ps, py);
+    hipLaunchKernelGGL((add_layernorm_kernel<true, true>), grid, block, 0, s, px, pr, pg, pb, eps, rows, C, ps, py, drop_group);
   else
-    hipLaunchKernelGGL((add_layernorm_kernel<true, false>), grid, block, 0, s, px, pr, pg, pb, eps, rows, C, ps, py);
+    hipLaunchKernelGGL((add_layernorm_kernel<true, false>), grid, block, 0, s, px, pr, pg, pb, eps, rows, C, ps, py, drop_group);
   return vc::check_launch();
 }
 

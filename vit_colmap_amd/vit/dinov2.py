@@ -233,7 +233,7 @@ class DinoV2(nn.Module):
             x = torch.empty((B, 1 + hp * wp, self.arch.dim), dtype=torch.bfloat16, device=patches.device)
             ops.patch_embed(patches, self._pe_w, self.patch_embed.proj.bias, pos, x)
             x[:, 0] = (self.cls_token[0, 0].float() + pos[0, 0].float()).to(torch.bfloat16)
-            return self._blocks_hip(x)[:, 1:]
+            return self._blocks_hip(x)
         x = self.patch_embed.forward_patches(patches)
         x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.interpolated_pos_embed(hp, wp)
         if self.register_tokens is not None:
@@ -277,9 +277,10 @@ class DinoV2(nn.Module):
         ) for b in self.blocks]
         return self
 
-    def _blocks_hip(self, x):
+    def _blocks_hip(self, x, drop_cls: bool = True):
         """ViT-S bf16 path on the hand-written GEMMs: LayerNorm lives in the x load of qkv / fc1, GELU and
-        both residual adds in GEMM epilogues; per block 4 kernels (the MLP is one) and no standalone elementwise pass."""
+        both residual adds in GEMM epilogues; per block 4 kernels (the MLP is one) and no standalone elementwise pass.
+        x (B, 1 + T, C) incl. the class token -> normalised patch tokens (B, T, C), or all rows with drop_cls=False."""
         from . import hip_ops as ops
 
         for blk, hw in zip(self.blocks, self._hip):
@@ -291,6 +292,8 @@ class DinoV2(nn.Module):
             hdn = hw["fc1"](x, ops.EPI_GELU, gelu_table=self._gelu_tab)   # gelu(fc1(LN2 x)), GELU by LDS table
             fc2 = blk.mlp.fc2
             ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=x, out=x)   # x += fc2(hdn)
+        if drop_cls:   # final norm of the patch tokens only: the class-token row is dropped here, the caller gets a dense tensor
+            return ops.layernorm_drop_first(x, self.norm.weight, self.norm.bias, self.norm.eps)
         _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
         return h
 
@@ -302,7 +305,7 @@ class DinoV2(nn.Module):
         if getattr(self, "_hip", None) is None:
             self.prepare_hip()
         if self._hip:
-            return self._blocks_hip(x)
+            return self._blocks_hip(x, drop_cls=False)
         blocks = list(self.blocks)
         _, h = add_layernorm(x, None, blocks[0].norm1.weight, blocks[0].norm1.bias, 1e-6)
         for i, blk in enumerate(blocks):

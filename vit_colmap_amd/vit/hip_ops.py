@@ -20,6 +20,17 @@ def add_layernorm(x: torch.Tensor, residual, weight: torch.Tensor, bias: torch.T
     return s, y
 
 
+def layernorm_drop_first(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    """x (B, N, C) bf16 -> LayerNorm of rows 1.. of every image as a dense (B, N - 1, C) tensor (the class-token row is
+    neither normalised nor copied)."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 3
+    B, N, C = x.shape
+    y = torch.empty((B, N - 1, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().vc_layernorm_drop_first_bf16(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), eps, B, N, C, _lib.ptr(y),
+                                                        _lib.stream_ptr()), "vc_layernorm_drop_first_bf16")
+    return y
+
+
 Q_PRESCALE = 0.125 * 1.4426950408889634   # 1/sqrt(64) * log2(e): what `q_prescaled=True` expects folded into q
 
 
