@@ -122,12 +122,20 @@ void run(const uint8_t* w, size_t w_bytes, uint32_t* out, int cus) {
          bytes_cu * cus / (ms * 1e-3) / 1e12, sg[0], sg[1], sg[2]);
 }
 
-int main(int argc, char**) {
+int main(int argc, char** argv) {
   const size_t w_bytes = 2304 * 1024;
   uint8_t* w; uint32_t* out;
   hipMalloc(&w, w_bytes); hipMemset(w, 1, w_bytes);
   hipMalloc(&out, 256 * 512 * 4 + 256 * 8 * 4 * 4);
-  const bool wide = argc > 1;                           // any argument: the 48 KiB-stage variants only
+  const bool hot = argc > 1 && argv[1][0] == 'h';       // "hot": the skeleton on weight buffers of 288 KiB .. 2.25 MiB (proj .. MLP size)
+  if (hot) {
+    for (size_t kb : {288, 864, 1152, 2304}) {
+      printf("weight buffer %zu KiB: ", kb);
+      run<2, 3, 24, true, 1, 8>(w, kb * 1024, out, 256);
+    }
+    return 0;
+  }
+  const bool wide = argc > 1;                           // any other argument: the 48 KiB-stage variants only
   for (int cus : {256, 64}) {
     if (wide) {
       if (cus != 256) continue;
