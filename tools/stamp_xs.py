@@ -20,6 +20,13 @@ for name, (N, epi, ln) in {"qkv": (1152, 0, True), "proj": (384, 2, False), "fc1
     torch.cuda.synchronize()
     d = o.view(-1)[: 256 * 8 * 8 * 2].view(torch.int32).cpu().numpy().astype(np.int64).reshape(256, 8, 8)
     print(f"== {name} (N={N}, epi={epi}, ln={ln})")
+    if os.environ.get("STEADY") == "1":   # -DVC_XS_STAMP -DVC_XS_STAMP_STEADY build: totals from iteration 2 on, slot 6 = stages counted
+        st = d[:, :, 6].astype(np.float64)
+        for i, nme in enumerate(["vmcnt wait", "barrier", "issue (+ x reload at tile switches)", "bias + MFMAs (+ epilogue slices)"]):
+            v = d[:, :, i].astype(np.float64) / np.maximum(st, 1)
+            print(f"    per stage and wave: {nme:38s} {v.mean():7.0f} cycles")
+        print(f"    per stage and wave: {'sum':38s} {(d[:, :, :4].sum(-1) / np.maximum(st, 1)).mean():7.0f} cycles")
+        continue
     for half, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
         print(" ", half)
         for i, nme in enumerate(names):

@@ -581,6 +581,12 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   int mt_cur = -1, slot = 0;
   int mt = s0 / n_nb, nb = s0 - mt * n_nb;
   for (int i = 0; i < n; ++i) {
+#if defined(VC_XS_STAMP) && defined(VC_XS_STAMP_STEADY)
+    if (i == 2) {   // steady-state totals: drop the pipeline fill and the first row tile's load (st_c[6] = stages counted)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st_c[k] = 0;
+    }
+#endif
     // This wave's pieces of stage i (issued in iteration i-2) have landed once only operations issued after
     // them are pending: per iteration a wave issues 3 pieces, then (residual epilogue) 2 loads, then the 2
     // result stores of the pending block — 7 (+4) from iteration 3 on, fewer while the pipeline fills.
@@ -674,7 +680,11 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   for (int sl = 0; sl < XKS; ++sl) slice(sl);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped refills before the LDS is released
 #ifdef VC_XS_STAMP
+#ifdef VC_XS_STAMP_STEADY
+  st_c[6] = (uint32_t)(n > 2 ? n - 2 : 0);
+#else
   XS_STAMP(6)
+#endif
   st_c[7] = (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0);
   if (lane < 8) {
     uint32_t v = 0;
