@@ -2,7 +2,11 @@
 """Benchmark of the vit-colmap hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this
+process is one rank and WORLD_SIZE must equal --gpus; without one, the process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, before anything has touched
+the GPU, and exits with that job's code.  A run that cannot have N ranks fails loudly (exit 2).
 
 One step = one pass of the hot path over one batch of synthetic input that is already resident
 in HBM (BASELINE.json configs[1] + configs[2] at N = 1):
@@ -13,11 +17,13 @@ in HBM (BASELINE.json configs[1] + configs[2] at N = 1):
 `value` = images/s of that whole step (all ranks).  Nothing is copied to the host inside the timed
 region; SQLite writes are host work outside the accelerated path and are not timed here.
 
-The matcher leg of BASELINE's metric is defined on fixed-size blocks (N = 512 keypoints, D = 384,
-all 1225 pairs: configs[2]) because the reference's NMS keeps a data-dependent
-~115 keypoints per image.  It is measured in the same run by a second timed loop of the same
-number of launches with HIP events on the launch stream; `pair_matches_per_s` and the `roofline`
-object come from that loop (rank 0).
+The matcher leg of BASELINE's metric is defined on fixed-size blocks (N = 512 keypoints, D = 384, all pairs
+among 50 blocks per GPU: configs[2]) because the reference's NMS keeps a data-dependent ~115
+keypoints per image.  It is measured in the same run by a second timed loop of launches with HIP events on the
+launch stream (every rank matches its share of the pairs among the 50*N blocks; the slowest rank's time counts);
+`pair_matches_per_s` and the `roofline` object come from that loop.  `pair_matches_per_s_dense` is the same loop
+on "scene" descriptors (SIFT-like, overlapping views: every similarity tile is relevant), the regime real
+descriptors of overlapping images are in.
 
 `cpu_baseline` (rank 0, N = 1 only): the CPU oracle (a port of the reference's algorithm, see
 oracle/) timed on the box's host cores on a bounded sample of the same workload.
@@ -25,12 +31,10 @@ oracle/) timed on the box's host cores on a bounded sample of the same workload.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -44,11 +48,47 @@ MATCH_BYTES_PER_PAIR = 2 * NUM_KEYPOINTS * DESC_DIM + 2 * NUM_KEYPOINTS * 12   #
 MATCH_OPS_PER_PAIR = 2.0 * NUM_KEYPOINTS * NUM_KEYPOINTS * DESC_DIM
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16
+TRAFFIC_PROFILE = "profiles/r02_matcher_traffic.json"   # rocprofv3 --pmc pass of this command (tools/prof_pmc.sh)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default: > 1 s of timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--match-launches", type=int, default=0,
+                    help="launches of the matcher micro-loops (default: enough for ~0.5 s each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def start_ranks(args):
+    """No launcher: become one.  Runs before this process has made any GPU call (torch is imported, the GPU is
+    not initialised: device_count() does not do that on this image), so no process that has touched the GPU is
+    ever replaced or re-executed; the ranks are fresh children."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); refusing to report fewer ranks "
+              "than asked for", file=sys.stderr)
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def synthetic_frames(rank, n):
     """640x480 BGR checkerboards (tile 40, reference tests/test_smoke_e2e.py:10-17) shifted per image
     plus seeded uniform noise (seed 1000 + global index) — SURVEY.md §8d."""
+    import numpy as np
+
     base = np.zeros((H, W, 3), np.uint8)
     for y in range(0, H, 40):
         for x in range(0, W, 40):
@@ -65,8 +105,9 @@ def synthetic_frames(rank, n):
 
 
 def c3_descriptor_blocks(n_images):
-    """Matcher micro-bench input of SURVEY.md §8d / BASELINE.md §3."""
-    from oracle.matcher_oracle import synthetic_descriptors   # data generator only (numpy)
+    """Matcher micro-bench input of SURVEY.md §8d / BASELINE.md §3 (tests/util_data.py: numpy only)."""
+    import numpy as np
+    from util_data import synthetic_descriptors
 
     return np.stack([synthetic_descriptors(k, NUM_KEYPOINTS, DESC_DIM) for k in range(n_images)])
 
@@ -83,8 +124,10 @@ def host_cores():
     return n
 
 
-def cpu_baseline(frames, steps_hint):
+def cpu_baseline(frames):
     """Oracle timed on the host: ViT + selection on a few images, C matcher on a sample of pairs."""
+    import numpy as np
+    import torch
     from oracle import c_oracle, select_oracle, vit_oracle
     from oracle import matcher_oracle as mo
     from oracle import preprocess_oracle as po
@@ -120,24 +163,35 @@ def cpu_baseline(frames, steps_hint):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            start_ranks(args)                     # does not return
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:                    # a line with n_gpus != --gpus would be read as an N-GPU result
+            if rank == 0:
+                print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+            sys.exit(2)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        world = dist.get_world_size()             # what was actually initialised
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    from util_data import image_set
     from vit_colmap_amd import dist as vd
     from vit_colmap_amd.features.vit_extractor import ViTExtractor
     from vit_colmap_amd.matching import match_pairs, prepare_descriptors
@@ -182,6 +236,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         res = step(False)
     barrier()
@@ -189,50 +250,69 @@ def main():
     for _ in range(args.steps):
         res = step(True)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # ---- matcher leg at the BASELINE shape (configs[2]): 50 x 512 x 384, 1225 pairs, rank 0 ----------
-    roof = pair_rate = None
-    if rank == 0:
-        c3 = torch.from_numpy(c3_descriptor_blocks(IMAGES_PER_RANK)).to(dev)
-        c3_counts = torch.full((IMAGES_PER_RANK,), NUM_KEYPOINTS, dtype=torch.int32, device=dev)
-        c3_pairs = torch.from_numpy(vd.pairs_for_rank(IMAGES_PER_RANK, 0, 1)).to(dev)
-        P = c3_pairs.shape[0]
-        cm = torch.empty((P, NUM_KEYPOINTS, 2), dtype=torch.int32, device=dev)
-        cc = torch.empty((P,), dtype=torch.int32, device=dev)
-        prepared = prepare_descriptors(c3, c3_counts)
-        for _ in range(max(args.warmup, 2)):
-            match_pairs(prepared, c3_counts, IMAGES_PER_RANK, NUM_KEYPOINTS, DESC_DIM, c3_pairs, out_matches=cm, out_counts=cc)
+    # ---- matcher leg at the BASELINE shape (configs[2]): 50 blocks of 512 x 384 per GPU, all pairs, this rank's share ----
+    def matcher_loop(blocks_np):
+        blocks = torch.from_numpy(blocks_np).to(dev)
+        counts = torch.full((n_global,), NUM_KEYPOINTS, dtype=torch.int32, device=dev)
+        P = my_pairs.shape[0]
+        prepared = prepare_descriptors(blocks, counts)
+        for _ in range(3):
+            match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                                          # HIP events on the stream the kernel is launched on
-        for _ in range(args.steps):
-            match_pairs(prepared, c3_counts, IMAGES_PER_RANK, NUM_KEYPOINTS, DESC_DIM, c3_pairs, out_matches=cm, out_counts=cc)
+        match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
         e1.record()
         torch.cuda.synchronize()
-        launch_ms = e0.elapsed_time(e1) / args.steps
-        pair_rate = P / launch_ms * 1e3
-        achieved = P * MATCH_BYTES_PER_PAIR / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_matcher_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roof = {
-            "kernel": "pair_kernel<12,2,true> (fused int8-MFMA similarity + top-2 + ratio/cross-check)",
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "launch_ms": round(launch_ms, 4), "pairs_per_launch": P, "bytes_per_pair": MATCH_BYTES_PER_PAIR,
-            "int8_tops": round(P * MATCH_OPS_PER_PAIR / (launch_ms * 1e-3) / 1e12, 1),
-        }
+        n = args.match_launches or max(20, min(20000, int(500.0 / max(e0.elapsed_time(e1), 1e-3))))   # ~0.5 s
+        barrier()
+        e0.record()
+        for _ in range(n):
+            match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
+        e1.record()
+        torch.cuda.synchronize()
+        launch_ms = e0.elapsed_time(e1) / n                  # this rank's kernel: P pairs per launch
+        slowest_ms = max_over_ranks(launch_ms)
+        return P, n, launch_ms, slowest_ms, int(out_c.sum().item())
+
+    P, n_launch, launch_ms, slowest_ms, _ = matcher_loop(c3_descriptor_blocks(n_global))
+    pair_rate = n_pairs_global / slowest_ms * 1e3            # whole job: all ranks' pairs / slowest rank's launch
+    dense_np, _ = image_set(1, n_global, NUM_KEYPOINTS, DESC_DIM, kind="scene")
+    Pd, n_launch_d, launch_ms_d, slowest_ms_d, dense_matches = matcher_loop(dense_np)
+    pair_rate_dense = n_pairs_global / slowest_ms_d * 1e3
 
     if rank == 0:
+        achieved = P * MATCH_BYTES_PER_PAIR / (launch_ms * 1e-3) / 1e9          # rank 0's launch, rank 0's GPU
+        achieved_d = Pd * MATCH_BYTES_PER_PAIR / (launch_ms_d * 1e-3) / 1e9
+        traffic = traffic_src = None
+        tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
+        if world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_src = f"{TRAFFIC_PROFILE}: PMC passes of this command, not a measurement of this run"
+        roof = {
+            "kernel": "pair_kernel (fused int8-MFMA similarity + row/column top-2 + ratio/cross-check)",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "launch_ms": round(launch_ms, 4), "launches_timed": n_launch, "pairs_per_launch": P,
+            "bytes_per_pair": MATCH_BYTES_PER_PAIR,
+            "int8_tops": round(P * MATCH_OPS_PER_PAIR / (launch_ms * 1e-3) / 1e12, 1),
+        }
+        roof_dense = {
+            "kernel": roof["kernel"], "bound": "hbm", "achieved": round(achieved_d, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved_d / HBM_PEAK_GBS, 4), "traffic": None,
+            "launch_ms": round(launch_ms_d, 4), "launches_timed": n_launch_d, "pairs_per_launch": Pd,
+            "bytes_per_pair": MATCH_BYTES_PER_PAIR,
+            "int8_tops": round(Pd * MATCH_OPS_PER_PAIR / (launch_ms_d * 1e-3) / 1e12, 1),
+            "matches_per_launch": dense_matches,
+            "input": "tests/util_data.image_set(kind='scene'): every image a noisy subset of one descriptor pool, so "
+                     "every 32x32 similarity tile holds relevant entries (the update path runs everywhere)",
+        }
         images = n_global * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         extract_ms = leg_ms["extract"] / args.steps
+        vit_tflops = VIT_FLOP_PER_IMAGE * IMAGES_PER_RANK / (extract_ms * 1e-3) / 1e12
         line = {
             "metric": "images/sec extracted + pair-matches/sec (N×D brute-force NN)",
             "value": round(images / elapsed, 2), "unit": "images/s",
@@ -247,20 +327,23 @@ def main():
                 "descriptor_dim": DESC_DIM, "pairs_per_step": n_pairs_global, "parallelism": f"images+pairs sharded x{world}",
                 "keypoints_kept_per_image_mean": round(float(res["count"].float().mean().item()), 1),
             },
+            "timed_region_s": round(elapsed, 3),
             "extract_images_per_s": round(IMAGES_PER_RANK * world / (extract_ms * 1e-3), 1),
             "pair_matches_per_s": round(pair_rate, 1),
-            "pair_matches_config": "configs[2]: 50 blocks of 512x384 uint8, all 1225 pairs, one launch",
+            "pair_matches_per_s_dense": round(pair_rate_dense, 1),
+            "pair_matches_config": f"configs[2] per GPU: {n_global} blocks of 512x384 uint8, all {n_pairs_global} pairs dealt "
+                                   f"round-robin to {world} rank(s), one launch per rank, slowest rank's time",
             "legs_ms_per_step_rank0": {k: round(v / args.steps, 3) for k, v in leg_ms.items()},
             "roofline": roof,
+            "roofline_dense": roof_dense,
             "roofline_vit": {
-                "bound": "mfma", "achieved": round(VIT_FLOP_PER_IMAGE * IMAGES_PER_RANK / (extract_ms * 1e-3) / 1e12, 1),
-                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(VIT_FLOP_PER_IMAGE * IMAGES_PER_RANK / (extract_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "bound": "mfma", "achieved": round(vit_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(vit_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                 "note": "whole extract leg (preprocess + ViT + selection) against the ViT's FLOPs: a lower bound on the GEMM rate",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(frames_np, args.steps)
+            line["cpu_baseline"] = cpu_baseline(frames_np)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

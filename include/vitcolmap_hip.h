@@ -95,8 +95,11 @@ int vc_mutual_ratio(const int32_t* idx12, const int32_t* best12, const int32_t* 
                     float max_ratio, float max_distance, int cross_check, uint32_t* out_pairs,
                     int32_t* out_count, vc_stream_t stream);
 
-/* Test hook: out[s] = theta(s) = angle assigned to integer similarity s, for s in [0, n). */
+/* Test hooks: out[s] = theta(s) = angle assigned to integer similarity s, for s in [0, n).
+ * vc_theta_table reads the table the pair kernel's acceptance tests use (generated at build time by
+ * csrc/gen_theta_table.c, clamped at s = 512^2); vc_theta_eval evaluates the same expression on the device. */
 int vc_theta_table(float* out, int n, vc_stream_t stream);
+int vc_theta_eval(float* out, int n, vc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Keypoint selection + descriptors over the ViT token grid — replaces

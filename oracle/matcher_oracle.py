@@ -134,11 +134,3 @@ def pair_id(image_id1: int, image_id2: int) -> int:
     if image_id1 > image_id2:
         image_id1, image_id2 = image_id2, image_id1
     return image_id1 * 2147483647 + image_id2
-
-
-def synthetic_descriptors(k: int, n: int, d: int) -> np.ndarray:
-    """Matcher micro-bench input: RandomState(2000+k) normal (n, d),
-    L2-normalised, quantised with the reference's own rule (vit_extractor.py:250)."""
-    x = np.random.RandomState(2000 + k).standard_normal((n, d)).astype(np.float32)
-    x /= np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))
-    return np.clip(x * np.float32(512.0), 0, 255).astype(np.uint8)

@@ -38,9 +38,11 @@ def test_theta_table_exhaustive():
     from vit_colmap_amd.matching import theta_table
 
     n = mo.S_SAT + 4
-    g = theta_table(n).cpu().numpy()
+    g = theta_table(n).cpu().numpy()                       # the build-time table the pair kernel reads (clamped)
+    e = theta_table(n, evaluate=True).cpu().numpy()        # the same expression evaluated on the device
     o = mo.theta_f32(np.arange(n))
     assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    assert np.array_equal(e.view(np.uint32), o.view(np.uint32))
 
 
 @pytest.mark.parametrize("n1,n2,d", [(512, 512, 384), (300, 300, 128), (33, 65, 128), (1, 7, 64),
@@ -136,3 +138,41 @@ def test_full_size_checksum_properties_c3():
     assert np.array_equal(gc, oc)
     for p in range(len(pairs)):
         assert np.array_equal(gm[p, :gc[p]], om[p, :oc[p]])
+
+
+# ---- the persistent kernel's own structure: ranges of pairs per workgroup, A reuse, the ring across pairs ----------
+@pytest.mark.parametrize("n_images,n_max,d,kind", [(40, 96, 128, "scene"), (27, 160, 256, "scene"), (33, 64, 64, "vit"),
+                                                   (24, 512, 384, "scene")])
+def test_persistent_ranges_more_pairs_than_cus(n_images, n_max, d, kind):
+    """More pairs than CUs (every workgroup walks several pairs, reusing image a), ragged and EMPTY images in
+    between, images shorter than the LDS ring (the producer runs into the next pair and has to idle)."""
+    rs = np.random.RandomState(n_images)
+    counts = rs.randint(1, n_max + 1, n_images).astype(np.int32)
+    counts[[3, 4, n_images - 1]] = 0                      # empty images: runs of pairs without work
+    counts[[5, 6]] = [1, 32]                              # one column tile: shorter than the ring
+    counts[7] = n_max
+    desc, counts = image_set(100 + n_images, n_images, n_max, d, kind=kind, counts=counts, noise=0.1)
+    pairs = mo.exhaustive_pairs(n_images)
+    gc = assert_batch_equal(desc, counts, pairs)
+    if kind == "scene":
+        assert gc.sum() > 500
+    # a pair list that is NOT sorted by image a, with repeats and self pairs (ranges then reload A more often)
+    perm = rs.permutation(len(pairs))[: 300]
+    shuffled = np.ascontiguousarray(np.concatenate([pairs[perm], pairs[perm[:7], ::-1], [[7, 7]]]).astype(np.int32))
+    assert_batch_equal(desc, counts, shuffled)
+
+
+@pytest.mark.parametrize("n_pairs", [1, 2, 7, 255, 256, 257, 263])
+def test_persistent_ranges_pair_counts_around_the_grid_size(n_pairs):
+    n_images, n_max, d = 24, 64, 128
+    desc, counts = image_set(55, n_images, n_max, d, kind="scene", noise=0.1)
+    pairs = np.ascontiguousarray(mo.exhaustive_pairs(n_images)[:n_pairs])
+    assert_batch_equal(desc, counts, pairs)
+
+
+def test_persistent_multi_pass_pairs_share_image_a():
+    """n > 512 rows: several row passes per pair (A changes every pass), three pairs in one range."""
+    n_images, n_max, d = 4, 1100, 128
+    counts = np.array([1100, 700, 513, 1024], np.int32)
+    desc, counts = image_set(77, n_images, n_max, d, kind="scene", counts=counts, noise=0.1)
+    assert_batch_equal(desc, counts, mo.exhaustive_pairs(n_images))

@@ -36,3 +36,11 @@ def image_set(seed, n_images, n_max, d, kind="scene", counts=None, noise=0.2):
         else:
             raise ValueError(kind)
     return desc, counts
+
+
+def synthetic_descriptors(k: int, n: int, d: int) -> np.ndarray:
+    """Matcher micro-bench input: RandomState(2000+k) normal (n, d),
+    L2-normalised, quantised with the reference's own rule (vit_extractor.py:250)."""
+    x = np.random.RandomState(2000 + k).standard_normal((n, d)).astype(np.float32)
+    x /= np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))
+    return np.clip(x * np.float32(512.0), 0, 255).astype(np.uint8)

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITCOLMAP_HIP_LIB") or os.path.join(_HERE, "libvitcolmap_hip.so")
 
 VC_OK = 0
+ABI_VERSION = 1
 VC_MAX_KEYPOINTS = 2048
 VC_MAX_DESC_DIM = 1024
 
@@ -37,6 +38,7 @@ SIGNATURES = {
     "vc_mutual_ratio": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "vc_theta_table": (c_int, [c_void_p, c_int, c_void_p]),
+    "vc_theta_eval": (c_int, [c_void_p, c_int, c_void_p]),
     "vc_structure_tensor": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_score_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_select_keypoints": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
@@ -71,6 +73,60 @@ SIGNATURES = {
 _lib = None
 
 
+class _DevPtr(c_void_p):
+    """Device pointer that remembers which GPU it lives on (see `_guarded`)."""
+    device = None
+
+
+class _AutoStream:
+    """Placeholder for "the current stream of the device the tensor arguments live on"."""
+
+
+_AUTO_STREAM = _AutoStream()
+
+
+def _guarded(fn, name):
+    """Wrap one C-ABI entry point so that it always runs on the GPU its tensors live on.
+
+    The library launches on the stream it is handed and asks HIP for the *current* device (CU counts, per-device
+    kernel attributes), so a call with tensors on cuda:1 while cuda:0 is current would dereference cuda:1 memory
+    from a cuda:0 kernel.  Every pointer made by `ptr()` carries its tensor's device; the call is refused when
+    they disagree, runs under `torch.cuda.device(that device)`, and a `stream_ptr()` placeholder becomes that
+    device's current stream."""
+
+    def call(*args):
+        devices = {a.device for a in args if isinstance(a, _DevPtr) and a.device is not None}
+        if len(devices) > 1:
+            raise HipLibraryError(f"{name}: tensor arguments live on different devices: {sorted(map(str, devices))}")
+        if not devices:
+            if any(a is _AUTO_STREAM for a in args):
+                import torch
+
+                args = tuple(c_void_p(torch.cuda.current_stream().cuda_stream) if a is _AUTO_STREAM else a for a in args)
+            return fn(*args)
+        import torch
+
+        dev = devices.pop()
+        with torch.cuda.device(dev):
+            args = tuple(c_void_p(torch.cuda.current_stream(dev).cuda_stream) if a is _AUTO_STREAM else a for a in args)
+            return fn(*args)
+
+    call.__name__ = name
+    return call
+
+
+class _Library:
+    """The loaded shared object: one guarded callable per entry point of SIGNATURES."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)  # AttributeError here = ABI drift between header and library
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, _guarded(fn, name) if c_void_p in args else fn)
+
+
 def load():
     """Load the shared object once and attach signatures.  Raises if it is missing."""
     global _lib
@@ -80,13 +136,9 @@ def load():
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `make -C vit_colmap_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
-        fn.restype = res
-        fn.argtypes = args
-    if lib.vc_abi_version() != 1:
-        raise HipLibraryError(f"ABI version {lib.vc_abi_version()} != 1")
+    lib = _Library(ctypes.CDLL(LIB_PATH))
+    if lib.vc_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI version {lib.vc_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 
@@ -99,12 +151,17 @@ def check(status, what):
 
 
 def stream_ptr(stream=None):
-    import torch
-
-    s = stream if stream is not None else torch.cuda.current_stream()
-    return c_void_p(s.cuda_stream)
+    """The stream argument of a C-ABI call: an explicit torch stream, or (default) the current stream of the
+    device the call's tensors live on, resolved inside the guarded call."""
+    if stream is None:
+        return _AUTO_STREAM
+    return c_void_p(stream.cuda_stream)
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None)."""
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device pointer of a torch tensor (or None); remembers the tensor's device for the guarded call."""
+    if t is None:
+        return None
+    p = _DevPtr(t.data_ptr())
+    p.device = t.device if t.is_cuda else None
+    return p

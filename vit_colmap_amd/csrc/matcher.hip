@@ -69,6 +69,28 @@ __device__ inline bool accept_dev(int best, int second, float max_ratio, float m
   return true;
 }
 
+// theta(s) for every s in [0, 512^2], generated at build time by gen_theta_table.c (same expression as
+// theta_dev; compared entry by entry on the device and against the oracle in tests/test_matcher_gpu.py).
+// With it the acceptance tests of a row are two L2-resident loads, a multiply and two compares: no
+// double-precision acos in the pair kernel, hence no register pressure from it around the pair loop.
+__device__ inline unsigned int umin(unsigned int a, unsigned int b);
+__device__ const uint32_t kThetaBits[512 * 512 + 1] = {
+#include "theta_table.inc"
+};
+__device__ __forceinline__ float theta_tab(int s) {
+  return __uint_as_float(kThetaBits[umin((u32)s, 512u * 512u)]);   // (unsigned clamp: no index is ever out of the table)
+}
+// accept_dev with table angles.  `s_low` (relevance_threshold): a best <= s_low is rejected whatever the
+// runner-up is, so those rows never touch the table (on non-matching image pairs that is every row).
+__device__ __forceinline__ bool accept_tab(int best, int second, float max_ratio, float max_distance, int s_low) {
+  if (best <= 0 || best <= s_low) return false;
+  const float tb = theta_tab(best);
+  const float ts = theta_tab(second);
+  if (tb > max_distance) return false;
+  if (tb >= max_ratio * ts) return false;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // cross-lane helpers (wave64; reductions run inside each 32-lane half)
 // ---------------------------------------------------------------------------------------
@@ -201,7 +223,14 @@ __device__ inline void wg_barrier() {
 // s_waitcnt vmcnt(0) before the next LDS read of the issuing wave, which drains the prefetch
 // it has just started.  Hidden in asm, the copy is invisible to the compiler's counters; the
 // kernel waits for it by hand (vmcnt(0) in the issuing wave, then the workgroup barrier).
-__device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst) {
+__device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst_any) {
+  // The destination is wave-uniform by construction, but under SGPR pressure the compiler may have computed it
+  // with vector instructions; an explicit v_readfirstlane (which it cannot fold away) puts it where M0 can take it.
+  // (The value is laundered through an empty asm so that the builtin is not folded away as "already uniform"; the
+  // v_readfirstlane itself is the compiler's, which knows the wait state it needs after the VALU write of its
+  // source — one written in asm right behind a v_mov read a stale register.)
+  asm volatile("" : "+v"(lds_dst_any));
+  const u32 lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
   u32 keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -436,6 +465,96 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
 #else
   asm volatile("" :: "v"(cb), "v"(cs2));
 #endif
+}
+
+// ---------------------------------------------------------------------------------------
+// Phases of the persistent kernel (pair2_kernel): accumulators that start from the row term
+// ---------------------------------------------------------------------------------------
+// MFMA phase with C = row term: acc[rt][4q + i] starts at rterm[32 rt + 8 q + 4 h + i] (the row that register
+// holds in the 32x32 MFMA C layout), read from the wave's LDS slice straight into the accumulator registers,
+// so the result is sum (a-128)(b-128) + 128 ra - 49024 D and the column term is all that is left to add.
+template <int KS, typename Mid>
+__device__ __forceinline__ void mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], const uint8_t* slot,
+                                            const int* rterm_wave, int lane, int h, Mid mid) {
+  constexpr int RT = 2;
+  constexpr int G = (RT * KS >= 24) ? 2 : (KS < 4 ? KS : 4);
+  constexpr int NG = KS / G;
+  static_assert(KS % G == 0, "KS must be a multiple of the fragment group");
+  const uint8_t* src = slot + lane * 16;
+  __builtin_amdgcn_s_setprio(1);
+  v4i bf[2][G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
+      acc[rt][4 * q + 0] = cr[0]; acc[rt][4 * q + 1] = cr[1]; acc[rt][4 * q + 2] = cr[2]; acc[rt][4 * q + 3] = cr[3];
+    }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) bf[(g + 1) & 1][i] = *(const v4i*)(src + ((g + 1) * G + i) * kFragBytes);
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][g * G + i], bf[g & 1][i], acc[rt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g == 0) mid();
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// Epilogue with the row term already inside the accumulators: s = acc + ct (ct: the lane's column term).
+//   relevance: some lane holds acc > s_low - ct                       (8 v_max3 + 1 compare per 32x32 tile)
+//   update   : key = (acc << 6) + ((ct << 6) | code)                  (one v_lshl_add per key)
+// The relevance test is cheap enough to run on every tile, so there is no separate "dense" regime here.
+// Column merge as in epilogue_phase.
+__device__ __forceinline__ void epilogue_phase2(const v16i (&acc)[2], u32 (&rbest)[2][16], u32 (&rsec)[2][16],
+                                                const int* cterm, unsigned long long* colbest, u32* colsecond,
+                                                int jt, int c, int h, u32 row_base, int s_low) {
+  constexpr int RT = 2;
+  const int ct = cterm[jt * kTile + c];
+  const int thr = s_low == 0x7fffffff ? s_low : s_low - ct;   // acc > thr  <=>  acc + ct > s_low (|ct| < 2^27: no overflow)
+  const u32 ctj = ((u32)ct << 6) + (63u - (u32)jt);           // key = (acc << 6) + ctj   (acc + ct >= 0)
+  u32 cb = 0, cs2 = 0;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int m = acc[rt][0];
+#pragma unroll
+    for (int r = 1; r < 16; r += 2) m = max(m, r + 1 < 16 ? max(acc[rt][r], acc[rt][r + 1]) : acc[rt][r]);
+    if (__any(m > thr)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const u32 rk = ((u32)acc[rt][r] << 6) + ctj;
+        rsec[rt][r] = umed3(rbest[rt][r], rsec[rt][r], rk);
+        rbest[rt][r] = umax(rbest[rt][r], rk);
+        const u32 ck = (rk & ~63u) | (u32)(63 - (rt * kTile + (r & 3) + 8 * (r >> 2)));
+        cs2 = umed3(cb, cs2, ck);
+        cb = umax(cb, ck);
+      }
+      // Keep the updates INSIDE the branch: without these ties the optimiser sinks the 32 med3 / max below the
+      // join with a zero key on the other path, i.e. runs them for every tile (seen in the ISA).
+#pragma unroll
+      for (int r = 0; r < 16; r += 4)
+        asm volatile("" : "+v"(rbest[rt][r]), "+v"(rbest[rt][r + 1]), "+v"(rbest[rt][r + 2]), "+v"(rbest[rt][r + 3]),
+                          "+v"(rsec[rt][r]), "+v"(rsec[rt][r + 1]), "+v"(rsec[rt][r + 2]), "+v"(rsec[rt][r + 3]));
+    }
+  }
+  if (cb != 0) {
+    const int j = jt * kTile + c;
+    const u32 sb = cb >> 6;
+    const u32 grow = row_base + (63u - (cb & 63u)) + 4u * h;
+    const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
+    const unsigned long long old = atomicMax(&colbest[j], key);
+    u32 cand = key > old ? (u32)(old >> 32) : sb;
+    cand = umax(cand, cs2 >> 6);
+    atomicMax(&colsecond[j], cand);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -928,6 +1047,295 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// The persistent pair kernel (KS <= 12, two row tiles per wave): what vc_match_pairs_u8 launches.
+// ---------------------------------------------------------------------------------------
+// Same arithmetic, tile loop and LDS layout as pair_kernel<KS, 2, true>; what differs is everything AROUND
+// the tile loop, which is where a workgroup of pair_kernel spent a third of its time with the matrix pipe idle
+// (measured: a launch with epilogue, staging and finalisation compiled out still ran at 55 % of the int8 peak):
+//   * one workgroup per CU walks a CONTIGUOUS range of the pair list.  The exhaustive list is ordered by
+//     image a, so consecutive pairs share it: the A fragments (96 VGPRs per wave, 192 KiB per workgroup) are
+//     re-fetched only when a (or the row pass) changes, not once per pair;
+//   * the B ring never drains: the producer cursor runs over the flattened (pair, pass, column tile) sequence,
+//     so the first tiles of the next pair are already in LDS while the current one is finalised;
+//   * the next pair's column sums are fetched into registers before the current pair's tile loop;
+//   * the angle / ratio tests read theta from a table (accept_tab) — no double-precision acos, so the
+//     finalisation is short and its registers do not collide with the fragments that stay live across it;
+//   * the accumulators start from the row term (read from LDS as the MFMA's C operand) instead of zero: the
+//     relevance test of a 32x32 tile is then a maximum over the lane's 16 accumulators against a per-lane
+//     threshold (9 VALU instead of 24), and an update key is one shift-add.
+// Block -> range mapping: blocks b and b + 8 share an XCD (round robin), so ranges are dealt such that each
+// XCD owns a contiguous eighth of the pair list (neighbouring pairs share image a in that XCD's L2).
+struct PairInfo {     // wave-uniform description of one pair with work (n_ct * n_pass > 0)
+  int p;              // index in the pair list (>= hi: none)
+  int a, n1, n2, n_ct, n_pass;
+  const uint8_t* b_frags;
+};
+
+// first pair at or after `p` that has tiles to process (scalar loads; runs once per pair, outside the tile loop)
+__device__ __forceinline__ PairInfo next_pair_with_work(int p, int hi, const int32_t* __restrict__ pairs,
+                                                        const int32_t* __restrict__ counts, int n_max,
+                                                        const uint8_t* __restrict__ prepared, size_t img_stride) {
+  PairInfo r;
+  r.a = 0; r.n1 = 0; r.n2 = 0; r.n_ct = 0; r.n_pass = 0; r.b_frags = prepared;
+  for (; p < hi; ++p) {
+    const int a = pairs[2 * p], b = pairs[2 * p + 1];
+    const int n1 = min(max(counts[a], 0), n_max), n2 = min(max(counts[b], 0), n_max);
+    if (n1 > 0 && n2 > 0) {
+      r.a = a; r.n1 = n1; r.n2 = n2;
+      r.n_ct = ceil_div(n2, kTile);
+      r.n_pass = ceil_div(n1, kWaves * 2 * kTile);
+      r.b_frags = prepared + (size_t)b * img_stride;
+      break;
+    }
+  }
+  r.p = p;
+  return r;
+}
+
+template <int KS>
+__global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
+    const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
+    const int32_t* __restrict__ pairs, int n_pairs, float max_ratio, float max_distance, int cross_check,
+    int n_max, int ns, int s_low, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts) {
+  static_assert(kWaves == 8, "the persistent kernel is written for eight-wave workgroups");
+  constexpr int RT = 2;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int n_pad = n_tiles_img * kTile;
+  uint8_t* ring = smem;
+  unsigned long long* colbest = (unsigned long long*)(smem + (size_t)ns * KS * kFragBytes);
+  u32* colsecond = (u32*)(colbest + n_pad);
+  int* cterm = (int*)(colsecond + n_pad);
+  int* m21 = cterm + n_pad;
+  int* rbest_s = m21 + n_pad;
+  int* rsecond_s = rbest_s + n_pad;
+  int* ridx_s = rsecond_s + n_pad;
+  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D
+  int* wave_count = crow6 + kWaves * 64 + kWaves * kRowScratchBytes / 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  uint2* rscratch = (uint2*)(crow6 + kWaves * 64) + wave * kRowScratchEntries;  // this wave's slice
+  int* crow6_wave = crow6 + wave * 64;
+  const size_t img_stride = image_bytes(n_tiles_img, KS);
+  const size_t frag_bytes_img = (size_t)n_tiles_img * KS * kFragBytes;
+  const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
+
+  // this workgroup's range of the pair list
+  const int G = gridDim.x;
+  const int cid = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int lo = (int)(((long long)cid * n_pairs) / G);
+  const int hi = (int)(((long long)(cid + 1) * n_pairs) / G);
+
+  PairInfo cur = next_pair_with_work(lo, hi, pairs, counts, n_max, prepared, img_stride);
+  if (tid == 0)
+    for (int q = lo; q < cur.p && q < hi; ++q) out_counts[q] = 0;   // empty images: nothing can match
+  if (cur.p >= hi) return;
+  PairInfo nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride);
+
+  // ---- producer: a stream of column tiles over (pair, pass, tile), PF tiles ahead of the consumer ----------
+  // It sweeps the current pair's image b once per row pass, then moves on to the NEXT pair (whose description is
+  // already in registers), so the ring stays full across the pair boundary.  It never runs more than one pair
+  // ahead: a next pair shorter than the ring leaves it idle until the consumer gets there.
+  const int pf = ns - 1;
+  const uint8_t* p_src = cur.b_frags;      // next tile to stage
+  const uint8_t* p_base = cur.b_frags;
+  int p_left = cur.n_ct, p_nct = cur.n_ct, p_sweeps = cur.n_pass;
+  bool p_on_next = false, p_active = true;
+  int prod_seq = 0, prod_slot = 0, cons_seq = 0, cons_slot = 0;
+  auto produce = [&]() {
+    if (p_active) {
+      stage_tile<KS>(p_src, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
+      ++prod_seq;
+      if (++prod_slot == ns) prod_slot = 0;
+      p_src += KS * kFragBytes;
+      if (--p_left == 0) {
+        if (--p_sweeps > 0) {
+          p_src = p_base; p_left = p_nct;
+        } else if (!p_on_next && nxt.p < hi) {
+          p_on_next = true;
+          p_src = p_base = nxt.b_frags; p_left = p_nct = nxt.n_ct; p_sweeps = nxt.n_pass;
+        } else {
+          p_active = false;
+        }
+      }
+    }
+  };
+  for (int i = 0; i < pf; ++i) produce();
+
+  // The two waves of a SIMD (w and w + 4) run half a tile apart, see pair_kernel.
+  const bool late = wave >= kWaves / 2;
+  v4i afrag[RT][KS];
+  int cur_a = -1, cur_tile0 = -1;
+  v16i acc[RT];   // (the late half's first epilogue of a pass looks at stale accumulators behind an unreachable threshold)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0;
+
+  while (true) {
+    const int p = cur.p;
+    const int n1 = cur.n1, n2 = cur.n2, n_ct = cur.n_ct, n_pass = cur.n_pass;
+    const uint8_t* a_frags = prepared + (size_t)cur.a * img_stride;
+    const int32_t* a_rowsum = (const int32_t*)(a_frags + frag_bytes_img);
+    const int32_t* b_rowsum = (const int32_t*)(cur.b_frags + frag_bytes_img);
+
+    // ---- per-pair LDS state (the previous pair's finalisation ended with a barrier) ---------------------------
+    for (int j = tid; j < n_ct * kTile; j += kThreads) {
+      cterm[j] = 128 * b_rowsum[j] + 32640 * d;
+      colbest[j] = 0ull;
+      colsecond[j] = 0u;
+    }
+    for (int i = tid; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+      const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
+      if (cur.a != cur_a || tile0 != cur_tile0) {     // wave-uniform: a new image a or a new row pass
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+            afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
+        // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows); the slice is
+        // wave-private and its LDS operations execute in order
+        crow6_wave[lane] = 128 * a_rowsum[tile0 * kTile + lane] - 49024 * d;
+        cur_a = cur.a;
+        cur_tile0 = tile0;
+        // The fragments must have landed before the tile loop: left pending, the compiler's own wait counts for
+        // their first use land INSIDE the loop (vmcnt(0) after the last MFMA) and drain the LDS-DMA prefetch of
+        // every tile.  vmcnt(0), other counters untouched (gfx9 encoding); a builtin, so the compiler sees it.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+      u32 rbest[RT][16], rsec[RT][16];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
+      const u32 row_base = (u32)(tile0 * kTile);
+
+      for (int jt = 0; jt < n_ct; ++jt) {
+        wait_tile<KS>(wave, prod_seq - cons_seq - 1);
+        wg_barrier();
+        const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
+        if (++cons_slot == ns) cons_slot = 0;
+        ++cons_seq;
+        if (!late) mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+        const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
+        const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
+        epilogue_phase2(acc, rbest, rsec, cterm, colbest, colsecond, ejt, c, h, row_base, eth);
+        if (late) mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+      }
+      if (late) epilogue_phase2(acc, rbest, rsec, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low);
+
+      // ---- row results of this pass (see pair_kernel) --------------------------------------------------------
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          u32 seen = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) seen |= rbest[rt][8 * half + j];
+          if (!__any(seen != 0)) continue;   // the 16 rows keep the (0, 0, -1) defaults
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * half + j;
+            rscratch[(j + 8 * h) * 33 + c] = make_uint2(rbest[rt][r], rsec[rt][r]);
+          }
+          const int rl = lane >> 2, qd = lane & 3;       // row of the round, column quarter
+          u32 rb = 0, rs = 0, rc = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint2 en = rscratch[rl * 33 + qd * 8 + e];
+            const bool gt = en.x > rb;
+            rs = gt ? umax(rb, en.y) : umax(rs, en.x);
+            rc = gt ? (u32)(qd * 8 + e) : rc;
+            rb = umax(rb, en.x);
+          }
+#pragma unroll
+          for (int step = 0; step < 2; ++step) {
+            u32 pb, ps, pc;
+            if (step == 0) { pb = dpp_mov<0xB1>(rb); ps = dpp_mov<0xB1>(rs); pc = dpp_mov<0xB1>(rc); }   // quad_perm [1,0,3,2]
+            else           { pb = dpp_mov<0x4E>(rb); ps = dpp_mov<0x4E>(rs); pc = dpp_mov<0x4E>(rc); }   // quad_perm [2,3,0,1]
+            const bool gt = pb > rb;
+            rs = gt ? umax(rb, ps) : umax(rs, pb);
+            rc = gt ? pc : rc;
+            rb = umax(rb, pb);
+          }
+          const int jj = rl & 7, hh = rl >> 3;
+          const int lrow = (jj & 3) + 16 * half + 8 * (jj >> 2) + 4 * hh;
+          if (qd == 0) {
+            const int row = (tile0 + rt) * kTile + lrow;
+            if (row < n1) {
+              const int sb = (int)(rb >> 6);
+              rbest_s[row] = sb;
+              rsecond_s[row] = sb > 0 ? (int)(rs >> 6) : 0;
+              ridx_s[row] = sb > 0 ? (63 - (int)(rb & 63)) * kTile + (int)rc : -1;
+            }
+          }
+        }
+      }
+    }  // passes
+
+    __syncthreads();
+    // ---- angle + ratio tests, cross check, ordered compaction ---------------------------------------------------
+    if (cross_check) {
+      for (int j = tid; j < n2; j += kThreads) {
+        const unsigned long long kb = colbest[j];
+        const int row = (int)(0xFFFFFFFFu - (u32)kb);
+        m21[j] = accept_tab((int)(kb >> 32), (int)colsecond[j], max_ratio, max_distance, s_low) ? row : -1;
+      }
+      __syncthreads();
+    }
+    uint32_t* out = out_matches + (size_t)p * n_max * 2;
+    int base = 0;
+    for (int i0 = 0; i0 < n1; i0 += kThreads) {
+      const int i = i0 + tid;
+      bool ok = false;
+      int j = -1;
+      if (i < n1) {
+        j = ridx_s[i];
+        ok = accept_tab(rbest_s[i], rsecond_s[i], max_ratio, max_distance, s_low);
+        if (ok && cross_check) ok = (m21[j] == i);
+      }
+      const unsigned long long mask = __ballot(ok);
+      if (lane == 0) wave_count[wave] = __popcll(mask);
+      __syncthreads();
+      int before = base, chunk_total = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const int wc = wave_count[w];
+        before += w < wave ? wc : 0;
+        chunk_total += wc;
+      }
+      if (ok) {
+        const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
+        out[2 * pos] = (uint32_t)i;
+        out[2 * pos + 1] = (uint32_t)j;
+      }
+      base += chunk_total;
+      __syncthreads();
+    }
+    if (tid == 0) {
+      out_counts[p] = base;
+      for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;   // empty images between this pair and the next
+    }
+
+    // ---- on to the next pair with work ---------------------------------------------------------------------------
+    if (nxt.p >= hi) break;
+    cur = nxt;
+    nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride);
+    if (p_on_next) {
+      p_on_next = false;               // the producer's pair is the consumer's pair again
+    }
+    if (!p_active && nxt.p < hi) {     // the producer had run out of described work: resume on the new next pair
+      p_active = true; p_on_next = true;
+      p_src = p_base = nxt.b_frags; p_left = p_nct = nxt.n_ct; p_sweeps = nxt.n_pass;
+    }
+  }  // pairs
+}
+
+// ---------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------
 __global__ void mutual_ratio_kernel(const int32_t* idx12, const int32_t* best12, const int32_t* second12,
@@ -970,9 +1378,9 @@ __global__ void knn_setup_kernel(int32_t* meta, int n1, int n2) {
   meta[2] = 0;  meta[3] = 1;    // the pair
 }
 
-__global__ void theta_table_kernel(float* out, int n) {
+__global__ void theta_table_kernel(float* out, int n, int from_table) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n) out[s] = theta_dev(s);
+  if (s < n) out[s] = from_table ? theta_tab(s) : theta_dev(s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1045,16 +1453,41 @@ int launch_pair(const void* prepared, const int32_t* counts, int n_tiles, int d,
   const int ns = plan_slots(KS, n_pad);
   if (ns == 0 || (RT == 2 && ns < 3)) return VC_ERR_UNSUPPORTED;
   const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes(n_pad);
-  static thread_local size_t configured = 0;  // per instantiation: largest size enabled so far
-  if (smem > configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)pair_kernel<KS, RT, FUSED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return vc::fail(e);
-    configured = kLdsBytes;
-  }
+  static vc::PerDeviceOnce configured;  // per instantiation and device
+  if (int st = configured.run([] {
+        return hipFuncSetAttribute((const void*)pair_kernel<KS, RT, FUSED>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+      }))
+    return st;
   hipLaunchKernelGGL((pair_kernel<KS, RT, FUSED>), dim3(n_pairs), dim3(kThreads), smem, stream,
                      (const uint8_t*)prepared, counts, n_tiles, d, pairs, max_ratio, max_distance,
                      cross_check, n_max, ns, s_low, out_matches, out_counts, o_idx, o_best, o_second);
+  return vc::check_launch();
+}
+
+// The persistent kernel: one workgroup per CU, each walking a contiguous range of the pair list.
+template <int KS>
+int launch_pair2(const void* prepared, const int32_t* counts, int n_tiles, int d, const int32_t* pairs,
+                 int n_pairs, float max_ratio, float max_distance, int cross_check, int n_max,
+                 uint32_t* out_matches, int32_t* out_counts, hipStream_t stream) {
+  const int s_low = relevance_threshold(max_ratio, max_distance);
+  const int n_pad = n_tiles * kTile;
+  const int ns = plan_slots(KS, n_pad);
+  if (ns < 3) return VC_ERR_UNSUPPORTED;
+  const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes(n_pad);
+  static vc::PerDeviceOnce configured;
+  if (int st = configured.run([] {
+        return hipFuncSetAttribute((const void*)pair2_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+      }))
+    return st;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const int grid = n_pairs < cus ? n_pairs : cus;
+  hipLaunchKernelGGL((pair2_kernel<KS>), dim3(grid), dim3(kThreads), smem, stream, (const uint8_t*)prepared, counts,
+                     n_tiles, d, pairs, n_pairs, max_ratio, max_distance, cross_check, n_max, ns, s_low, out_matches,
+                     out_counts);
   return vc::check_launch();
 }
 
@@ -1111,6 +1544,17 @@ int vc_match_pairs_u8(const void* prepared, const int32_t* counts, int n_images,
   if (n_images <= 0 || n_max <= 0 || d <= 0 || n_pairs < 0) return VC_ERR_INVALID_ARG;
   if (n_max > VC_MAX_KEYPOINTS || d > VC_MAX_DESC_DIM) return VC_ERR_UNSUPPORTED;
   if (n_pairs == 0) return VC_OK;
+#if VC_WAVES == 8 && !defined(VC_OLD_PAIR_KERNEL)
+  switch (pick_ks(d)) {   // descriptors up to 384 bytes: the persistent kernel (two row tiles per wave)
+#define VC_CASE2(K)                                                                                          \
+  case K:                                                                                                    \
+    return launch_pair2<K>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio, max_distance,   \
+                           cross_check, n_max, out_matches, out_counts, (hipStream_t)stream);
+    VC_CASE2(2) VC_CASE2(4) VC_CASE2(8) VC_CASE2(12)
+#undef VC_CASE2
+    default: break;
+  }
+#endif
   return dispatch_pair<true>(pick_ks(d), prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio,
                              max_distance, cross_check, n_max, out_matches, out_counts, nullptr,
                              nullptr, nullptr, (hipStream_t)stream);
@@ -1168,7 +1612,14 @@ int vc_mutual_ratio(const int32_t* idx12, const int32_t* best12, const int32_t* 
 int vc_theta_table(float* out, int n, vc_stream_t stream) {
   if (!out || n < 0) return VC_ERR_INVALID_ARG;
   if (n == 0) return VC_OK;
-  hipLaunchKernelGGL(theta_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n);
+  hipLaunchKernelGGL(theta_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, 1);
+  return vc::check_launch();
+}
+
+int vc_theta_eval(float* out, int n, vc_stream_t stream) {
+  if (!out || n < 0) return VC_ERR_INVALID_ARG;
+  if (n == 0) return VC_OK;
+  hipLaunchKernelGGL(theta_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, 0);
   return vc::check_launch();
 }
 

@@ -513,13 +513,12 @@ int vc_score_map(const float* st, int n_images, int H, int W, int method, float*
   if ((long)H * W > kMaxCells) return VC_ERR_UNSUPPORTED;
   if (n_images == 0) return VC_OK;
   const size_t smem = ((size_t)2 * H * W + 32) * sizeof(float);
-  static thread_local bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((2 * kMaxCells + 32) * sizeof(float)));
-    if (e != hipSuccess) return vc::fail(e);
-    configured = true;
-  }
+  static vc::PerDeviceOnce configured;
+  if (int st = configured.run([] {
+        return hipFuncSetAttribute((const void*)score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((2 * kMaxCells + 32) * sizeof(float)));
+      }))
+    return st;
   // kernel sizes as the reference derives them: k = int(6 sigma + 1), made odd (vit_extractor.py:371-374)
   const Taps g3 = make_taps(3, 1.0f), g7 = make_taps(7, 1.0f), g11 = make_taps(11, 1.6f);
   hipLaunchKernelGGL(score_kernel, dim3(n_images), dim3(kSelThreads), smem, (hipStream_t)stream, st, H, W,
@@ -545,13 +544,11 @@ int vc_select_keypoints(const float* score, int n_images, int H, int W, int targ
   const size_t smem = (size_t)cells * 4 * 2 + (size_t)kMaxCandidates * 4 * 5;
   constexpr int kDynMax = 160 * 1024 - 1024;  // the kernel also has a few static LDS words
   if (smem > (size_t)kDynMax) return VC_ERR_UNSUPPORTED;
-  static thread_local bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kDynMax);
-    if (e != hipSuccess) return vc::fail(e);
-    configured = true;
-  }
+  static vc::PerDeviceOnce configured;
+  if (int st = configured.run([] {
+        return hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDynMax);
+      }))
+    return st;
   hipLaunchKernelGGL(select_kernel, dim3(n_images), dim3(kSelThreads), smem, (hipStream_t)stream, score, H, W,
                      target, bin_size, nms_radius, kmax, out_yx, out_score, out_count, dbg_cand_yx,
                      dbg_cand_score, dbg_cand_count);

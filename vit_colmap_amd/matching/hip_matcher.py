@@ -93,8 +93,10 @@ def mutual_ratio(r12, r21, n1, n2, max_ratio=0.8, max_distance=0.7, cross_check=
     return out, cnt
 
 
-def theta_table(n: int, device="cuda") -> torch.Tensor:
+def theta_table(n: int, device="cuda", evaluate: bool = False) -> torch.Tensor:
+    """theta(s) for s in [0, n): the table the pair kernel reads, or (evaluate=True) the device's own evaluation."""
     lib = _lib.load()
     out = torch.empty((n,), dtype=torch.float32, device=device)
-    _lib.check(lib.vc_theta_table(_lib.ptr(out), n, _lib.stream_ptr()), "vc_theta_table")
+    fn, name = (lib.vc_theta_eval, "vc_theta_eval") if evaluate else (lib.vc_theta_table, "vc_theta_table")
+    _lib.check(fn(_lib.ptr(out), n, _lib.stream_ptr()), name)
     return out
