@@ -477,11 +477,17 @@ template <int KS, typename Mid>
 __device__ __forceinline__ void mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], const uint8_t* slot,
                                             const int* rterm_wave, int lane, int h, Mid mid) {
   constexpr int RT = 2;
+#ifdef VC2_G
+  constexpr int G = KS % VC2_G == 0 ? VC2_G : ((RT * KS >= 24) ? 2 : (KS < 4 ? KS : 4));
+#else
   constexpr int G = (RT * KS >= 24) ? 2 : (KS < 4 ? KS : 4);
+#endif
   constexpr int NG = KS / G;
   static_assert(KS % G == 0, "KS must be a multiple of the fragment group");
   const uint8_t* src = slot + lane * 16;
+#ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(1);
+#endif
   v4i bf[2][G];
 #pragma unroll
   for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
@@ -506,28 +512,32 @@ __device__ __forceinline__ void mfma_phase2(const v4i (&afrag)[2][KS], v16i (&ac
     __builtin_amdgcn_sched_barrier(0);
     if (g == 0) mid();
   }
+#ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // Epilogue with the row term already inside the accumulators: s = acc + ct (ct: the lane's column term).
 //   relevance: some lane holds acc > s_low - ct                       (8 v_max3 + 1 compare per 32x32 tile)
 //   update   : key = (acc << 6) + ((ct << 6) | code)                  (one v_lshl_add per key)
 // The relevance test is cheap enough to run on every tile, so there is no separate "dense" regime here.
-// Column merge as in epilogue_phase.
-__device__ __forceinline__ void epilogue_phase2(const v16i (&acc)[2], u32 (&rbest)[2][16], u32 (&rsec)[2][16],
-                                                const int* cterm, unsigned long long* colbest, u32* colsecond,
+// `ct` is read from LDS by the caller BEFORE the MFMA phase that precedes this call: read here it queued behind
+// the other waves' fragment reads (stamps: ~450 of an epilogue's 660 cycles).  Column merge as in epilogue_phase.
+__device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbest)[2][16], u32 (&rsec)[2][16],
+                                                int ct, unsigned long long* colbest, u32* colsecond,
                                                 int jt, int c, int h, u32 row_base, int s_low) {
   constexpr int RT = 2;
-  const int ct = cterm[jt * kTile + c];
   const int thr = s_low == 0x7fffffff ? s_low : s_low - ct;   // acc > thr  <=>  acc + ct > s_low (|ct| < 2^27: no overflow)
   const u32 ctj = ((u32)ct << 6) + (63u - (u32)jt);           // key = (acc << 6) + ctj   (acc + ct >= 0)
   u32 cb = 0, cs2 = 0;
+  bool hit = false;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     int m = acc[rt][0];
 #pragma unroll
     for (int r = 1; r < 16; r += 2) m = max(m, r + 1 < 16 ? max(acc[rt][r], acc[rt][r + 1]) : acc[rt][r]);
     if (__any(m > thr)) {
+      hit = true;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const u32 rk = ((u32)acc[rt][r] << 6) + ctj;
@@ -555,6 +565,7 @@ __device__ __forceinline__ void epilogue_phase2(const v16i (&acc)[2], u32 (&rbes
     cand = umax(cand, cs2 >> 6);
     atomicMax(&colsecond[j], cand);
   }
+  return hit;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1112,6 +1123,15 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D
   int* wave_count = crow6 + kWaves * 64 + kWaves * kRowScratchBytes / 4;
 
+#ifdef VC_EXP_STAMP
+  // diagnostic build: per-wave cycle totals over the workgroup's whole range (tools/stamp_matcher.py)
+  unsigned long long st_wait = 0, st_mfma = 0, st_epi = 0, st_init = 0, st_rowred = 0, st_final = 0;
+  const unsigned long long st_t0 = stamp();
+  unsigned long long st_tp = st_t0;
+#define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - st_tp; st_tp = t_; }
+#else
+#define VC_ST(acc_)
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1164,8 +1184,14 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   };
   for (int i = 0; i < pf; ++i) produce();
 
+  int* pair_flag = wave_count + kWaves;   // "some tile of the current pair was relevant"
+  int rb_pref = tid < cur.n_ct * kTile ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[tid] : 0;
   // The two waves of a SIMD (w and w + 4) run half a tile apart, see pair_kernel.
+#ifdef VC2_NO_STAGGER
+  constexpr bool late = false;
+#else
   const bool late = wave >= kWaves / 2;
+#endif
   v4i afrag[RT][KS];
   int cur_a = -1, cur_tile0 = -1;
   v16i acc[RT];   // (the late half's first epilogue of a pass looks at stale accumulators behind an unreachable threshold)
@@ -1182,12 +1208,17 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     const int32_t* b_rowsum = (const int32_t*)(cur.b_frags + frag_bytes_img);
 
     // ---- per-pair LDS state (the previous pair's finalisation ended with a barrier) ---------------------------
-    for (int j = tid; j < n_ct * kTile; j += kThreads) {
+    // (columns 0..511 come from the register fetched during the previous pair: the load's latency was 2 k cycles
+    // of every pair when it sat here)
+    if (tid < n_ct * kTile) { cterm[tid] = 128 * rb_pref + 32640 * d; colbest[tid] = 0ull; colsecond[tid] = 0u; }
+    for (int j = tid + kThreads; j < n_ct * kTile; j += kThreads) {
       cterm[j] = 128 * b_rowsum[j] + 32640 * d;
       colbest[j] = 0ull;
       colsecond[j] = 0u;
     }
     for (int i = tid; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
+    if (tid == 0) *pair_flag = 0;
+    bool pair_hit = false;   // some tile of this wave held a relevant similarity
 
     for (int pass = 0; pass < n_pass; ++pass) {
       const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
@@ -1213,20 +1244,33 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
       const u32 row_base = (u32)(tile0 * kTile);
+      VC_ST(st_init)
 
+      int ct = 0;   // column term of the tile whose epilogue comes next; always read ahead of an MFMA phase
       for (int jt = 0; jt < n_ct; ++jt) {
         wait_tile<KS>(wave, prod_seq - cons_seq - 1);
         wg_barrier();
         const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
         if (++cons_slot == ns) cons_slot = 0;
         ++cons_seq;
-        if (!late) mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+        VC_ST(st_wait)
+        if (!late) {
+          ct = cterm[jt * kTile + c];
+          mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+          VC_ST(st_mfma)
+        }
         const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
         const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-        epilogue_phase2(acc, rbest, rsec, cterm, colbest, colsecond, ejt, c, h, row_base, eth);
-        if (late) mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, colbest, colsecond, ejt, c, h, row_base, eth);
+        VC_ST(st_epi)
+        if (late) {
+          ct = cterm[jt * kTile + c];
+          mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+          VC_ST(st_mfma)
+        }
       }
-      if (late) epilogue_phase2(acc, rbest, rsec, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low);
+      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, colbest, colsecond, n_ct - 1, c, h, row_base, s_low);
+      VC_ST(st_epi)
 
       // ---- row results of this pass (see pair_kernel) --------------------------------------------------------
 #pragma unroll
@@ -1275,9 +1319,21 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
           }
         }
       }
+      VC_ST(st_rowred)
     }  // passes
 
+    // column sums of the next pair's image b (consumed by its LDS initialisation)
+    if (nxt.p < hi && tid < nxt.n_ct * kTile) rb_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[tid];
+    if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
     __syncthreads();
+    if (*pair_flag == 0) {
+      // No tile of the pair held a similarity above the relevance threshold: every row's best stays below what the
+      // angle test accepts, the match list is empty and nothing of the finalisation has to run.
+      if (tid == 0) {
+        out_counts[p] = 0;
+        for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;
+      }
+    } else {
     // ---- angle + ratio tests, cross check, ordered compaction ---------------------------------------------------
     if (cross_check) {
       for (int j = tid; j < n2; j += kThreads) {
@@ -1320,7 +1376,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       out_counts[p] = base;
       for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;   // empty images between this pair and the next
     }
+    }
+    __syncthreads();   // the flag and the per-pair state are rewritten by the next pair's initialisation
 
+    VC_ST(st_final)
     // ---- on to the next pair with work ---------------------------------------------------------------------------
     if (nxt.p >= hi) break;
     cur = nxt;
@@ -1333,6 +1392,14 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       p_src = p_base = nxt.b_frags; p_left = p_nct = nxt.n_ct; p_sweeps = nxt.n_pass;
     }
   }  // pairs
+#ifdef VC_EXP_STAMP
+  if (lane == 0) {
+    uint32_t* dbg = out_matches + ((size_t)lo * n_max + (n_max - 64)) * 2 + wave * 8;
+    dbg[0] = (uint32_t)st_wait; dbg[1] = (uint32_t)st_mfma; dbg[2] = (uint32_t)st_epi; dbg[3] = (uint32_t)st_init;
+    dbg[4] = (uint32_t)st_rowred; dbg[5] = (uint32_t)st_final; dbg[6] = (uint32_t)(stamp() - st_t0); dbg[7] = (uint32_t)(hi - lo);
+  }
+#endif
+#undef VC_ST
 }
 
 // ---------------------------------------------------------------------------------------
