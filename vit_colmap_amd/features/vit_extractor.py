@@ -82,19 +82,25 @@ class ViTExtractor(BaseExtractor):
         if projection is not None:
             self.set_projection(projection)
         self.timings = {"decode_s": 0.0, "gpu_s": 0.0, "db_s": 0.0, "images": 0}
-        # hipBLASLt's default heuristic is poor for the K = 384 shapes of ViT-S (fc1: 170 us vs 115 us
-        # tuned at 76 550 rows); TunableOp times the candidate kernels once per new GEMM shape (~1 s
-        # each, first batch only).  It is switched on only around the ViT forward (`_tokens`), never
-        # process-wide: it aborts on some unrelated float32 batched GEMMs.
-        self.tune_gemm = bool(tune_gemm) and self.device.type == "cuda"
+        # Wider backbones (ViT-B/L/g) still run their GEMMs on hipBLASLt, whose default heuristic is poor for these
+        # shapes; TunableOp times the candidate kernels once per new GEMM shape (~1 s each, first batch only).
+        # It is used ONLY for bf16 on models the hand-written GEMMs do not cover, only around the ViT forward
+        # (`_tokens`), never process-wide and never for float32: round 1 recorded a SIGABRT inside an unrelated
+        # float32 batched matmul while it was enabled process-wide ("TunableOp").  Results are kept in
+        # memory; a CSV is written only when VITCOLMAP_TUNABLEOP_CSV names one.
+        self.tune_gemm = (bool(tune_gemm) and self.device.type == "cuda" and self.dtype == torch.bfloat16
+                          and not getattr(self.model, "_hip", None))
         if self.tune_gemm:
             import os
-            import tempfile
             import torch.cuda.tunable as tunable
 
             tunable.set_max_tuning_duration(200)
             tunable.set_max_tuning_iterations(20)
-            tunable.set_filename(os.path.join(tempfile.gettempdir(), f"vitcolmap_tunableop_{os.getuid()}.csv"), True)  # one file per device
+            csv = os.environ.get("VITCOLMAP_TUNABLEOP_CSV")
+            if csv:
+                tunable.set_filename(csv, True)   # one file per device
+            else:
+                tunable.set_filename(os.devnull, False)   # this torch has no "do not write" switch: results stay in memory
         print("✓ ViT model ready")
 
     # ------------------------------------------------------------------------------------------
