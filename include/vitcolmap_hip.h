@@ -102,6 +102,26 @@ int vc_theta_table(float* out, int n, vc_stream_t stream);
 int vc_theta_eval(float* out, int n, vc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Two-view geometric verification, scoring half — the step that follows descriptor matching inside
+ * pycolmap.match_exhaustive (reference call site vit_colmap/pipeline/run_pipeline.py:351-363) and fills the
+ * two_view_geometries table the reference's metrics read (vit_colmap/utils/metrics.py:207-243).
+ * Specification: oracle/two_view_oracle.py.  Hypotheses are produced above the ABI (8x8 linear solves);
+ * everything that is O(pairs x hypotheses x matches) runs here.
+ *   pts      [total][4] float32 (x1, y1, x2, y2): the matched keypoints of all pairs, concatenated; 16-byte aligned
+ *   offsets  [n_pairs + 1] int32: pair p owns pts[offsets[p] .. offsets[p+1])
+ *   model    VC_MODEL_FUNDAMENTAL: row-major F, inlier iff (x2' F x1)^2 <= e^2 (|F x1|_xy^2 + |F' x2|_xy^2)  (Sampson)
+ *            VC_MODEL_HOMOGRAPHY : row-major H, inlier iff |(H x1)_xy - x2 (H x1)_w|^2 <= e^2 (H x1)_w^2      (transfer)
+ * vc_two_view_score:   hypotheses [n_pairs][n_hyp][9] -> out_counts [n_pairs][n_hyp] (NaN hypotheses count 0)
+ * vc_two_view_inliers: models [n_pairs][9] -> out_mask [total] uint8
+ * ------------------------------------------------------------------------------------------ */
+#define VC_MODEL_FUNDAMENTAL 0
+#define VC_MODEL_HOMOGRAPHY 1
+int vc_two_view_score(const float* pts, const int32_t* offsets, int n_pairs, const float* hypotheses, int n_hyp,
+                      int model, float max_error, int32_t* out_counts, vc_stream_t stream);
+int vc_two_view_inliers(const float* pts, const int32_t* offsets, int n_pairs, const float* models, int model,
+                        float max_error, uint8_t* out_mask, vc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Keypoint selection + descriptors over the ViT token grid — replaces
  * ViTExtractor._dense_to_sparse and helpers (reference vit_colmap/features/vit_extractor.py:168-653).
  * Specification: oracle/select_oracle.py.  All functions are batched over n_images.

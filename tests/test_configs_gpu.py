@@ -175,3 +175,44 @@ def test_c4_pair_count_200_images_properties_and_sampled_oracle():
     sp2 = np.ascontiguousarray(pairs.numpy()[sample[:40]])
     _, oc2, _ = c_oracle.match_pairs(blocks, np.full(n_images, n_max, np.int32), sp2)
     assert np.array_equal(c0.cpu().numpy()[sample[:40]], oc2)
+
+
+# ---- the reference's `--extractor trainable_vit` pipeline reaches matching (20 480 keypoints asked for) -----------------
+def test_trainable_vit_pipeline_extract_then_match(tmp_path):
+    """reference run_pipeline.py:326-333 builds TrainableViTExtractor(num_keypoints=20480, nms_radius=1, score_threshold=0.4);
+    images with more than VC_MAX_KEYPOINTS rows go through the sub-block matcher."""
+    from vit_colmap_amd import _lib
+    from vit_colmap_amd.database import ColmapDatabase
+    from vit_colmap_amd.pipeline import Pipeline
+    from vit_colmap_amd.utils import Config, image_io
+
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    rs = np.random.RandomState(2)
+    base = np.kron(rs.randint(0, 255, (50, 64, 3)), np.ones((16, 16, 1)))
+    for k in range(3):
+        img = np.roll(base, (11 * k, 7 * k), (1, 0)) + rs.randint(-25, 25, base.shape)
+        image_io.imwrite(img_dir / f"im_{k}.png", np.clip(img, 0, 255).astype(np.uint8))       # 800 x 1024
+    cfg = Config()
+    cfg.camera.model = "SIMPLE_RADIAL"
+    cfg.extractor.extractor_type = "trainable_vit"
+    cfg.do_matching, cfg.do_reconstruction = True, False
+    db_path = tmp_path / "t.db"
+    pipe = Pipeline(cfg)
+    pipe.run(img_dir, tmp_path / "out", db_path, dataset="synthetic", scene="boards", results_dir=tmp_path / "results")
+    with ColmapDatabase.open_database(str(db_path)) as h:
+        descs = [h.read_descriptors(i) for i in (1, 2, 3)]
+        assert all(d is not None and d.shape[1] == 128 for d in descs)
+        assert max(len(d) for d in descs) > _lib.VC_MAX_KEYPOINTS, [len(d) for d in descs]     # the blocked path really ran
+        assert h.num_matched_image_pairs() == 3
+        n_max = max(len(d) for d in descs)
+        block = np.zeros((3, n_max, 128), np.uint8)
+        for k, d in enumerate(descs):
+            block[k, : len(d)] = d
+        pairs = mo.exhaustive_pairs(3)
+        om, oc, _ = c_oracle.match_pairs(block, np.array([len(d) for d in descs], np.int32), pairs)
+        for p, (a, b) in enumerate(pairs):
+            assert np.array_equal(h.read_matches(int(a) + 1, int(b) + 1), om[p, : oc[p]])
+        assert h.read_two_view_geometry(1, 2) is not None                                      # one row per matched pair
+    assert (tmp_path / "results" / "synthetic" / "boards" / "trainable_vit.json").exists()
+    assert (tmp_path / "results" / "synthetic" / "summary.csv").exists()

@@ -90,3 +90,110 @@ def test_two_rank_gloo_pipeline(n_images):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results)
+
+
+# ---- the product entries (not just the helpers): match_exhaustive(distributed=True) and pipeline.run_sharded ------------
+def _oracle_match_fn(block, counts, pairs, max_ratio, max_distance, cross_check):
+    """Stand-in for the HIP matcher in this GPU-less container (same contract as matching.exhaustive.hip_match_blocks)."""
+    block, counts = np.asarray(block), np.asarray(counts)
+    return [mo.match_pair(block[a, : counts[a]], block[b, : counts[b]], max_ratio, max_distance, cross_check) for a, b in pairs]
+
+
+def _dump_db(path):
+    from vit_colmap_amd.database import ColmapDatabase
+
+    with ColmapDatabase.open_database(str(path)) as h:
+        imgs = [(im.image_id, im.name) for im in h.read_all_images()]
+        out = dict(images=imgs, pairs=h.num_matched_image_pairs())
+        for i, _ in imgs:
+            out[("kp", i)] = h.read_keypoints(i)
+            out[("d", i)] = h.read_descriptors(i)
+        for i, _ in imgs:
+            for j, _ in imgs:
+                if i < j:
+                    out[("m", i, j)] = h.read_matches(i, j)
+    return out
+
+
+def _same_db(a, b):
+    assert a["images"] == b["images"] and a["pairs"] == b["pairs"] and a.keys() == b.keys()
+    for k in a:
+        if isinstance(k, tuple):
+            assert (a[k] is None) == (b[k] is None), k
+            if a[k] is not None:
+                assert np.array_equal(a[k], b[k]), k
+
+
+def _make_feature_db(path, desc, counts):
+    from vit_colmap_amd.database import ColmapDatabase
+
+    db = ColmapDatabase(str(path))
+    cam = db.add_pinhole_camera(640, 480, 640, 640, 320, 240)
+    for k in range(len(counts)):
+        i = db.add_image(f"im{k:02d}.png", cam)
+        if counts[k]:
+            db.add_keypoints(i, np.zeros((counts[k], 2), np.float32))
+            db.add_descriptors(i, desc[k, : counts[k]])
+    db.db.close()
+
+
+def _product_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pathlib import Path
+
+        from vit_colmap_amd.features.dummy_extractor import DummyExtractor
+        from vit_colmap_amd.matching import match_exhaustive
+        from vit_colmap_amd.pipeline.distributed import run_sharded
+
+        tmp = Path(tmp)
+        # (1) database in, database out: rank 0 reads and writes, both ranks match their share
+        stats = match_exhaustive(database_path=str(tmp / "dist.db"), distributed=True, match_fn=_oracle_match_fn,
+                                 device="cpu", verify=False)
+        ok = stats["ranks"] == 2 and stats["pairs"] == 21
+        # (2) directory in, database out: image shards, one descriptor all-gather, pair shards, rank-0 writer
+        dummy = DummyExtractor(step=32)
+        st = run_sharded(tmp / "images", tmp / "sharded.db", "PINHOLE",
+                         feature_fn=lambda imgs: [dummy.features_for(*im.shape[:2]) for im in imgs],
+                         match_fn=_oracle_match_fn, verify=False, device="cpu", batch_size=2)
+        ok = ok and st["images"] == 5 and st["pairs"] == 10 and st["ranks"] == 2
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_product_entries_write_the_single_process_database(tmp_path):
+    from vit_colmap_amd.features.dummy_extractor import DummyExtractor
+    from vit_colmap_amd.matching import match_exhaustive
+    from vit_colmap_amd.utils import image_io
+
+    desc, counts = image_set(33, 7, 48, 64, kind="scene", counts=[48, 40, 0, 48, 17, 33, 48], noise=0.1)
+    for name in ("single.db", "dist.db"):
+        _make_feature_db(tmp_path / name, desc, counts)
+    (tmp_path / "images").mkdir()
+    from test_host_logic import checkerboard
+
+    for k in range(5):
+        image_io.imwrite(tmp_path / "images" / f"img_{k}.png", np.roll(checkerboard(), (13 * k, 7 * k), (1, 0)))
+    (tmp_path / "images" / "img_9_broken.png").write_bytes(b"not an image")          # unreadable: no row, no features
+
+    # single-process references (same stand-in matcher)
+    s = match_exhaustive(database_path=str(tmp_path / "single.db"), match_fn=_oracle_match_fn, device="cpu", verify=False)
+    assert s["pairs"] == 21 and s["matches"] > 50 and s["ranks"] == 1
+    DummyExtractor(step=32).extract(tmp_path / "images", tmp_path / "single_pipe.db", "PINHOLE")
+    match_exhaustive(database_path=str(tmp_path / "single_pipe.db"), match_fn=_oracle_match_fn, device="cpu", verify=False)
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_product_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(results)
+    _same_db(_dump_db(tmp_path / "single.db"), _dump_db(tmp_path / "dist.db"))
+    _same_db(_dump_db(tmp_path / "single_pipe.db"), _dump_db(tmp_path / "sharded.db"))

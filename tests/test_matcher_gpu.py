@@ -176,3 +176,24 @@ def test_persistent_multi_pass_pairs_share_image_a():
     counts = np.array([1100, 700, 513, 1024], np.int32)
     desc, counts = image_set(77, n_images, n_max, d, kind="scene", counts=counts, noise=0.1)
     assert_batch_equal(desc, counts, mo.exhaustive_pairs(n_images))
+
+
+# ---- more rows than one kernel block holds (VC_MAX_KEYPOINTS = 2048): sub-blocks + associative top-2 merge ------------
+@pytest.mark.parametrize("n1,n2,d", [(2500, 2049, 128), (4100, 1000, 64), (20480, 20480, 128)])
+def test_blocked_matcher_beyond_max_keypoints(n1, n2, d):
+    """The reference's trainable_vit pipeline asks for 20 480 keypoints per image (run_pipeline.py:328-333)."""
+    from vit_colmap_amd.matching.exhaustive import hip_match_blocks
+
+    n_max = max(n1, n2)
+    desc, counts = image_set(n1 + d, 2, n_max, d, kind="scene", counts=[n1, n2], noise=0.1)
+    desc[0, n1 // 3] = desc[0, 5]                         # duplicate rows: ties across sub-block boundaries
+    desc[1, min(n2 - 1, 2100)] = desc[1, 7]
+    pairs = np.array([[0, 1], [1, 0]], np.int32)
+    lists = hip_match_blocks(desc, counts, pairs)
+    om, oc, _ = c_oracle.match_pairs(desc, counts, pairs)
+    for p in range(2):
+        assert len(lists[p]) == oc[p] > 100
+        assert np.array_equal(lists[p], om[p, : oc[p]])
+    no_cc = hip_match_blocks(desc, counts, pairs[:1], cross_check=False)
+    om2, oc2, _ = c_oracle.match_pairs(desc, counts, pairs[:1], cross_check=False)
+    assert np.array_equal(no_cc[0], om2[0, : oc2[0]])

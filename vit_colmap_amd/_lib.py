@@ -39,6 +39,8 @@ SIGNATURES = {
                                 c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "vc_theta_table": (c_int, [c_void_p, c_int, c_void_p]),
     "vc_theta_eval": (c_int, [c_void_p, c_int, c_void_p]),
+    "vc_two_view_score": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "vc_two_view_inliers": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "vc_structure_tensor": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_score_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_select_keypoints": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,

@@ -10,7 +10,8 @@ reads [recalled schema, SURVEY.md §8b]:
   images(image_id AUTOINCREMENT, name UNIQUE, camera_id)
   keypoints / descriptors(image_id, rows, cols, data BLOB float32 / uint8, row-major)
   matches(pair_id, rows, cols, data BLOB uint32), pair_id = id1 * 2147483647 + id2, id1 < id2
-  two_view_geometries(...)  — created empty: geometric verification is outside the hot path
+  two_view_geometries(pair_id, rows, cols, data BLOB uint32 inlier matches, config, F, E, H, qvec, tvec BLOB float64)
+      — written by matching/two_view.py (geometric verification)
 """
 import sqlite3
 from contextlib import contextmanager
@@ -172,6 +173,31 @@ class SqliteColmapDatabase:
         if commit:
             self._conn.commit()
 
+    def write_two_view_geometry(self, image_id1: int, image_id2: int, inlier_matches: np.ndarray, config: int,
+                                F=None, E=None, H=None, qvec=None, tvec=None, commit: bool = True):
+        """One row per verified pair [recalled COLMAP layout]: inlier matches uint32 (rows, 2) relative to the smaller
+        image id, `config` (TwoViewGeometry::ConfigurationType: 1 DEGENERATE, 2 CALIBRATED, 3 UNCALIBRATED, 4 PLANAR,
+        5 PANORAMIC, 6 PLANAR_OR_PANORAMIC ... — the codes reference utils/metrics.py:131-141 names), and the
+        matrices as float64 blobs (F, E, H row-major 3x3; qvec 4, tvec 3).  A swapped pair transposes F / E and inverts
+        nothing else: the build always writes id1 < id2."""
+        m = np.asarray(inlier_matches, dtype=np.uint32).reshape(-1, 2)
+        swap = image_id1 > image_id2
+        if swap:
+            m = m[:, ::-1]
+        m = np.ascontiguousarray(m)
+
+        def blob(a, shape, transpose=False):
+            a = np.zeros(shape) if a is None else np.asarray(a, np.float64).reshape(shape)
+            return np.ascontiguousarray(a.T if transpose else a).tobytes()
+
+        self._conn.execute(
+            "INSERT OR REPLACE INTO two_view_geometries VALUES (?, ?, ?, ?, ?, ?, ?, ?, ?, ?)",
+            (pair_id_of(image_id1, image_id2), m.shape[0], 2, m.tobytes() if m.shape[0] else None, int(config),
+             blob(F, (3, 3), swap), blob(E, (3, 3), swap), blob(H, (3, 3)), blob(qvec if qvec is not None else [1, 0, 0, 0], (4,)),
+             blob(tvec, (3,))))
+        if commit:
+            self._conn.commit()
+
     def commit(self):
         self._conn.commit()
 
@@ -232,6 +258,26 @@ class SqliteColmapDatabase:
 
     def read_descriptors(self, image_id: int):
         return self._read_blob("descriptors", "image_id", image_id, np.uint8)
+
+    def num_verified_image_pairs(self) -> int:
+        return self._count("SELECT COUNT(*) FROM two_view_geometries WHERE rows > 0")
+
+    def num_inlier_matches(self) -> int:
+        return self._count("SELECT COALESCE(SUM(rows), 0) FROM two_view_geometries")
+
+    def read_two_view_geometry(self, image_id1: int, image_id2: int):
+        """-> dict(inlier_matches uint32 (rows, 2), config, F, E, H) or None."""
+        row = self._conn.execute("SELECT rows, cols, data, config, F, E, H FROM two_view_geometries WHERE pair_id = ?",
+                                 (pair_id_of(image_id1, image_id2),)).fetchone()
+        if row is None:
+            return None
+        rows, cols, data, config, F, E, H = row
+        m = np.zeros((0, 2), np.uint32) if rows == 0 or data is None else np.frombuffer(data, np.uint32).reshape(rows, cols).copy()
+        mats = [np.frombuffer(x, np.float64).reshape(3, 3).copy() if x is not None else np.zeros((3, 3)) for x in (F, E, H)]
+        if image_id1 > image_id2:
+            m = np.ascontiguousarray(m[:, ::-1])
+            mats[0], mats[1] = mats[0].T, mats[1].T
+        return dict(inlier_matches=m, config=int(config), F=mats[0], E=mats[1], H=mats[2])
 
     def read_matches(self, image_id1: int, image_id2: int):
         m = self._read_blob("matches", "pair_id", pair_id_of(image_id1, image_id2), np.uint32)

@@ -9,10 +9,27 @@ The reference is single-process; this module is the build's own 
   * pairs: the exhaustive pair list is dealt round-robin (pair p -> rank p % world), so every
     rank matches the same number of pairs (+-1) with no further communication;
   * results: match lists are gathered to rank 0, the single SQLite writer.
+Product entries built on it: `matching.match_exhaustive(..., distributed=True)` (database in, database out) and
+`pipeline.distributed.run_sharded` (what `Pipeline.run` calls when a process group with more than one rank exists).
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank_world():
+    return (dist.get_rank(), dist.get_world_size()) if is_distributed() else (0, 1)
+
+
+def comm_device(default="cuda"):
+    """Device collectives' tensors must live on: the GPU under RCCL ("nccl"), the host under gloo."""
+    if is_distributed() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return torch.device(default)
 
 
 def shard_range(n: int, rank: int, world: int):
@@ -39,7 +56,7 @@ def pair_index(n_images: int, a, b):
 def all_gather_descriptors(desc: torch.Tensor, counts: torch.Tensor):
     """desc uint8 (n_local, n_max, D), counts int32 (n_local,) -> the same for all ranks' images,
     concatenated in rank order.  Every rank must pass the same n_local (pad with count 0)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not is_distributed():
         return desc, counts
     world = dist.get_world_size()
     all_desc = torch.empty((world * desc.shape[0],) + tuple(desc.shape[1:]), dtype=desc.dtype, device=desc.device)
@@ -49,10 +66,63 @@ def all_gather_descriptors(desc: torch.Tensor, counts: torch.Tensor):
     return all_desc, all_counts
 
 
-def gather_match_lists(pairs: np.ndarray, counts: np.ndarray, matches: np.ndarray, dst: int = 0):
+def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """Any (n_local, ...) tensor -> (world * n_local, ...) in rank order (same n_local on every rank)."""
+    if not is_distributed():
+        return t
+    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def max_over_ranks(*values):
+    """Element-wise maximum of small non-negative integers over all ranks (block shapes that must agree)."""
+    if not is_distributed():
+        return tuple(int(v) for v in values)
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return tuple(int(v) for v in t.tolist())
+
+
+def broadcast_array(arr, src: int = 0, device=None):
+    """numpy array on `src` (anything elsewhere) -> the same array on every rank."""
+    if not is_distributed():
+        return arr
+    meta = [None]
+    if dist.get_rank() == src:
+        arr = np.ascontiguousarray(arr)
+        meta = [(arr.shape, arr.dtype.str)]
+    dist.broadcast_object_list(meta, src=src)
+    shape, dtype = meta[0]
+    dev = comm_device(device or "cuda")
+    if dist.get_rank() == src:
+        t = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev)
+    else:
+        t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8, device=dev)
+    if t.numel():
+        dist.broadcast(t, src=src)
+    return t.cpu().numpy().view(np.dtype(dtype)).reshape(shape)
+
+
+def gather_pair_lists(pairs: np.ndarray, lists, dst: int = 0):
     """Variable-length gather of (pair, match list) results to `dst` (host arrays; small).
-    Returns on dst a list of (pairs, counts, matches) per rank, elsewhere None."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    Returns on dst a dict {(a, b): uint32 (M, 2)} over all ranks' pairs, elsewhere None."""
+    if not is_distributed():
+        return {(int(a), int(b)): m for (a, b), m in zip(pairs, lists)}
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object((np.asarray(pairs), [np.asarray(m) for m in lists]), out, dst=dst)
+    if out is None:
+        return None
+    merged = {}
+    for prs, ls in out:
+        for (a, b), m in zip(prs, ls):
+            merged[(int(a), int(b))] = m
+    return merged
+
+
+def gather_match_lists(pairs: np.ndarray, counts: np.ndarray, matches: np.ndarray, dst: int = 0):
+    """Padded-array form of gather_pair_lists: returns on dst a list of (pairs, counts, matches) per rank."""
+    if not is_distributed():
         return [(pairs, counts, matches)]
     payload = (pairs, counts, [matches[p, : counts[p]].copy() for p in range(len(pairs))])
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None

@@ -120,6 +120,24 @@ class ViTExtractor(BaseExtractor):
             raise ValueError(f"projection must have shape (C, {self.descriptor_dim}), got {tuple(p.shape)}")
         self.descriptor_projection = p
 
+    def sync_projection(self, image_dir):
+        """Multi-GPU runs: fit the projection on rank 0 (first image, as the reference does) and broadcast it, so
+        that every rank projects with the same matrix."""
+        from .. import dist as vd
+
+        if not vd.is_distributed():
+            return
+        rank, _ = vd.rank_world()
+        if rank == 0 and self.descriptor_projection is None:
+            files = list_images(Path(image_dir))
+            first = image_io.imread(files[0]) if files else None
+            if first is not None:
+                self._run_batch([first])
+        have = vd.broadcast_array(np.array([self.descriptor_projection is not None], np.int32), 0, str(self.device))
+        if int(have[0]):
+            p = vd.broadcast_array(self.descriptor_projection.cpu().numpy() if rank == 0 else None, 0, str(self.device))
+            self.set_projection(p)
+
     def _require_gpu(self):
         if self.device.type != "cuda":
             raise _lib.HipLibraryError(

@@ -4,7 +4,13 @@ reference calls at vit_colmap/pipeline/run_pipeline.py:351-363, on the HIP match
 
 Reads every image's uint8 descriptors, matches all unordered pairs (a < b in image-id order) on
 the GPU, and writes one `matches` row per pair (also when it is empty, as COLMAP does [recalled]).
-`two_view_geometries` stays empty: geometric verification is outside the hot path.
+With `verify=True` (default) the match lists are then geometrically verified (matching/two_view.py) and
+`two_view_geometries` rows written, as `match_exhaustive` does inside COLMAP.
+
+Multi-GPU (`distributed=True`, or automatically when a torch.distributed group with more than one rank exists):
+rank 0 reads the database and broadcasts the descriptor blocks, the pair list is dealt round-robin over the
+ranks, every rank matches its share on its own GPU, the lists are gathered to rank 0 and rank 0 alone writes
+(vit_colmap_amd/dist.py).
 """
 import logging
 import time
@@ -13,6 +19,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import dist as vd
 from ..database.colmap_db import SqliteColmapDatabase
 from .hip_matcher import exhaustive_pairs, match_pairs, prepare_descriptors
 
@@ -46,53 +53,98 @@ def load_descriptor_blocks(db: SqliteColmapDatabase):
     return ids, block, counts, D
 
 
+def hip_match_blocks(block, counts, pairs, max_ratio=0.8, max_distance=0.7, cross_check=True, device="cuda",
+                     pair_chunk: int = 16384):
+    """uint8 blocks [n][n_max][D] + counts (host or device) and pairs int32 (P, 2) (host) -> list of P uint32 (M, 2)
+    match lists, on the HIP matcher.  Blocks with more rows than one kernel block holds (VC_MAX_KEYPOINTS) are
+    matched in row / column sub-blocks whose top-2 results are merged (hip_matcher.match_pairs_blocked)."""
+    if not torch.cuda.is_available():
+        raise _lib.HipLibraryError("the matcher is HIP-only (no CPU fallback): no GPU visible")
+    d_desc = block if torch.is_tensor(block) else torch.from_numpy(np.ascontiguousarray(block))
+    d_counts = counts if torch.is_tensor(counts) else torch.from_numpy(np.ascontiguousarray(counts, np.int32))
+    d_desc, d_counts = d_desc.to(device), d_counts.to(device)
+    n, n_max, D = d_desc.shape
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    if D > _lib.VC_MAX_DESC_DIM:
+        raise _lib.HipLibraryError(f"descriptors of {D} bytes exceed the kernels' limit ({_lib.VC_MAX_DESC_DIM})")
+    if n_max > _lib.VC_MAX_KEYPOINTS:
+        from .hip_matcher import match_pairs_blocked
+
+        return match_pairs_blocked(d_desc, d_counts, pairs, max_ratio, max_distance, cross_check)
+    prepared = prepare_descriptors(d_desc, d_counts)
+    out = []
+    for s in range(0, len(pairs), pair_chunk):
+        chunk = torch.from_numpy(pairs[s:s + pair_chunk]).to(device)
+        m, c = match_pairs(prepared, d_counts, n, n_max, D, chunk, max_ratio, max_distance, cross_check)
+        c_np = c.cpu().numpy()
+        m_np = m.cpu().numpy().view(np.uint32)
+        out.extend(m_np[p, : c_np[p]].copy() for p in range(len(c_np)))
+    return out
+
+
 def match_exhaustive(database_path: str, matching_options=None, sift_options=None, device="cuda",
-                     pair_chunk: int = 16384) -> dict:
-    """Returns a small stats dict (pairs, matches, seconds); the result proper is in the database."""
+                     pair_chunk: int = 16384, distributed=None, match_fn=None, verify: bool = True) -> dict:
+    """Returns a small stats dict (pairs, matches, seconds); the result proper is in the database.
+    `match_fn(block, counts, pairs, max_ratio, max_distance, cross_check) -> list of match lists` replaces the HIP
+    matcher (the CPU tests of the multi-rank path pass the oracle; the product never does)."""
     sift = _sift_options(matching_options, sift_options)
     max_ratio, max_distance, cross_check = float(sift.max_ratio), float(sift.max_distance), bool(sift.cross_check)
-    if not torch.cuda.is_available():
-        raise _lib.HipLibraryError("match_exhaustive needs an MI355X: the matcher is HIP-only (no CPU fallback)")
+    if distributed is None:
+        distributed = vd.is_distributed()
+    if distributed and not vd.is_distributed():
+        raise RuntimeError("distributed=True needs an initialised torch.distributed process group with > 1 rank")
+    rank, world = vd.rank_world() if distributed else (0, 1)
+    if match_fn is None:
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("match_exhaustive needs an MI355X: the matcher is HIP-only (no CPU fallback)")
+
+        def match_fn(block, counts, pairs, r, dmax, cc):
+            return hip_match_blocks(block, counts, pairs, r, dmax, cc, device=device, pair_chunk=pair_chunk)
+
     t0 = time.perf_counter()
-    db = SqliteColmapDatabase(str(database_path))
+    db = SqliteColmapDatabase(str(database_path)) if rank == 0 else None      # rank 0 is the only reader and writer
     try:
-        ids, block, counts, D = load_descriptor_blocks(db)
+        if rank == 0:
+            ids, block, counts, D = load_descriptor_blocks(db)
+        else:
+            ids = block = counts = D = None
+        if distributed:
+            meta = [(ids, D)]
+            torch.distributed.broadcast_object_list(meta, src=0)
+            ids, D = meta[0]
+            block = vd.broadcast_array(block, 0, device)
+            counts = vd.broadcast_array(counts, 0, device)
         n = len(ids)
-        stats = dict(images=n, pairs=n * (n - 1) // 2, matches=0, gpu_s=0.0, db_s=0.0)
+        stats = dict(images=n, pairs=n * (n - 1) // 2, matches=0, gpu_s=0.0, db_s=0.0, verified_pairs=0, ranks=world)
         if n < 2:
             return stats
-        pairs = exhaustive_pairs(n)
-        if D == 0 or block.shape[1] > _lib.VC_MAX_KEYPOINTS or D > _lib.VC_MAX_DESC_DIM:
-            if D != 0:
-                raise _lib.HipLibraryError(
-                    f"descriptor blocks of {block.shape[1]} x {D} exceed the kernels' limits "
-                    f"({_lib.VC_MAX_KEYPOINTS} keypoints, {_lib.VC_MAX_DESC_DIM} bytes)")
-            for a, b in pairs.numpy():   # no descriptors anywhere: every pair is empty
-                db.write_matches(ids[a], ids[b], np.zeros((0, 2), np.uint32), commit=False)
-            db.commit()
-            return stats
-        n_max = block.shape[1]
+        my_pairs = vd.pairs_for_rank(n, rank, world)
         t1 = time.perf_counter()
-        d_desc = torch.from_numpy(block).to(device)
-        d_counts = torch.from_numpy(counts).to(device)
-        prepared = prepare_descriptors(d_desc, d_counts)
-        for s in range(0, len(pairs), pair_chunk):
-            chunk = pairs[s:s + pair_chunk].contiguous()
-            m, c = match_pairs(prepared, d_counts, n, n_max, D, chunk.to(device), max_ratio, max_distance, cross_check)
-            c_np = c.cpu().numpy()
-            m_np = m.cpu().numpy().view(np.uint32)
-            torch.cuda.synchronize()
-            stats["gpu_s"] += time.perf_counter() - t1
+        if D == 0:
+            lists = [np.zeros((0, 2), np.uint32) for _ in my_pairs]          # no descriptors anywhere: every pair is empty
+        else:
+            lists = match_fn(block, counts, my_pairs, max_ratio, max_distance, cross_check)
+        stats["gpu_s"] = time.perf_counter() - t1
+        merged = vd.gather_pair_lists(my_pairs, lists, dst=0) if distributed else \
+            {(int(a), int(b)): m for (a, b), m in zip(my_pairs, lists)}
+        if rank == 0:
             t2 = time.perf_counter()
-            for p, (a, b) in enumerate(chunk.numpy()):
-                db.write_matches(ids[a], ids[b], m_np[p, : c_np[p]], commit=False)
+            for a, b in exhaustive_pairs(n).numpy():                           # COLMAP's pair order, whatever rank matched it
+                m = merged[(int(a), int(b))]
+                db.write_matches(ids[a], ids[b], m, commit=False)
+                stats["matches"] += len(m)
             db.commit()
-            stats["matches"] += int(c_np.sum())
-            stats["db_s"] += time.perf_counter() - t2
-            t1 = time.perf_counter()
+            if verify and D != 0:
+                from .two_view import verify_database_pairs
+
+                stats["verified_pairs"] = verify_database_pairs(db, ids, merged, device=device if torch.cuda.is_available() else "cpu")
+            stats["db_s"] = time.perf_counter() - t2
+        if distributed:
+            torch.distributed.barrier()
         stats["total_s"] = time.perf_counter() - t0
-        logger.info("matched %d pairs (%d matches): gpu %.3f s, db %.3f s", stats["pairs"], stats["matches"],
-                    stats["gpu_s"], stats["db_s"])
+        logger.info("matched %d pairs (%d matches) on %d rank(s): gpu %.3f s, db %.3f s", stats["pairs"], stats["matches"],
+                    world, stats["gpu_s"], stats["db_s"])
         return stats
     finally:
-        db.close()
+        if db is not None:
+            db.close()

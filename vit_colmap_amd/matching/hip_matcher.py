@@ -100,3 +100,59 @@ def theta_table(n: int, device="cuda", evaluate: bool = False) -> torch.Tensor:
     fn, name = (lib.vc_theta_eval, "vc_theta_eval") if evaluate else (lib.vc_theta_table, "vc_theta_table")
     _lib.check(fn(_lib.ptr(out), n, _lib.stream_ptr()), name)
     return out
+
+
+def match_pairs_blocked(desc: torch.Tensor, counts: torch.Tensor, pairs, max_ratio=0.8, max_distance=0.7,
+                        cross_check=True, block_rows: int = _lib.VC_MAX_KEYPOINTS):
+    """Image pairs whose blocks hold more rows than one kernel block (VC_MAX_KEYPOINTS) — e.g. the reference's
+    `trainable_vit` pipeline asks for 20 480 keypoints (run_pipeline.py:328-333).
+
+    Each image is cut into sub-blocks of `block_rows` rows; every (sub-block of a, sub-block of b) runs through the
+    one-way top-2 search in both directions (vc_knn_top2_u8) and the per-row results are merged over the
+    sub-blocks of the other image in ascending order — best and second-best are associative: a later sub-block
+    takes over only with a strictly larger similarity (so the lowest column index still wins ties) and the
+    displaced or the non-winning best becomes a runner-up candidate — then vc_mutual_ratio applies the angle /
+    ratio tests and the cross check to the merged arrays.  Bit-identical to the single-block path by construction
+    (tests/test_matcher_gpu.py compares both with the C oracle).
+
+    desc uint8 (n_images, n_max, D) on the GPU, counts int32 (n_images,), pairs int (P, 2) on the host.
+    Returns a list of P uint32 (M, 2) arrays."""
+    _need_cuda(desc, counts)
+    cnt = counts.cpu().numpy()
+    out = []
+    for a, b in np.asarray(pairs).reshape(-1, 2):
+        n1, n2 = int(cnt[a]), int(cnt[b])
+        if n1 == 0 or n2 == 0:
+            out.append(np.zeros((0, 2), np.uint32))
+            continue
+        da, db = desc[a, :n1], desc[b, :n2]
+        dev = desc.device
+        r12 = [torch.full((n1,), -1, dtype=torch.int32, device=dev), torch.zeros(n1, dtype=torch.int32, device=dev),
+               torch.zeros(n1, dtype=torch.int32, device=dev)]
+        r21 = [torch.full((n2,), -1, dtype=torch.int32, device=dev), torch.zeros(n2, dtype=torch.int32, device=dev),
+               torch.zeros(n2, dtype=torch.int32, device=dev)]
+
+        def merge(acc, lo, hi, idx, best, second, offset):
+            # rows lo..hi of the accumulated (idx, best, second) absorb one more sub-block of the other image
+            ai, ab, asec = acc[0][lo:hi], acc[1][lo:hi], acc[2][lo:hi]
+            gt = best > ab
+            new_sec = torch.where(gt, torch.maximum(ab, second), torch.maximum(asec, best))
+            acc[0][lo:hi] = torch.where(gt, idx + offset, ai)
+            acc[2][lo:hi] = new_sec
+            acc[1][lo:hi] = torch.maximum(ab, best)
+
+        for i0 in range(0, n1, block_rows):
+            i1 = min(i0 + block_rows, n1)
+            for j0 in range(0, n2, block_rows):      # ascending: the earlier sub-block keeps ties
+                j1 = min(j0 + block_rows, n2)
+                blk_a, blk_b = da[i0:i1].contiguous(), db[j0:j1].contiguous()
+                merge(r12, i0, i1, *knn_top2(blk_a, blk_b), j0)
+        for j0 in range(0, n2, block_rows):
+            j1 = min(j0 + block_rows, n2)
+            for i0 in range(0, n1, block_rows):
+                i1 = min(i0 + block_rows, n1)
+                merge(r21, j0, j1, *knn_top2(db[j0:j1].contiguous(), da[i0:i1].contiguous()), i0)
+        m, c = mutual_ratio(r12, r21, n1, n2, max_ratio, max_distance, cross_check)
+        k = int(c.item())
+        out.append(m[:k].cpu().numpy().view(np.uint32).copy())
+    return out

@@ -2,8 +2,8 @@
 extraction into the COLMAP database, exhaustive matching (reference
 vit_colmap/pipeline/run_pipeline.py:274-370, CLI :420-513).
 
-Everything after matching in the reference (incremental mapping, metrics export, plots) is outside
-the accelerated path.  `do_reconstruction=True` hands the database to pycolmap if it
+Incremental mapping and plots stay outside the accelerated path; the database metrics and their
+JSON / CSV export (§8f-3) are in utils/metrics.py and utils/export.py.  `do_reconstruction=True` hands the database to pycolmap if it
 is importable and otherwise logs that the step is skipped.
 """
 import argparse
@@ -53,21 +53,39 @@ class Pipeline:
         db_path.parent.mkdir(parents=True, exist_ok=True)
 
         extractor = self._make_extractor()
-        logger.info("Extracting features...")
-        extractor.extract(image_dir, db_path, camera_model, camera_params)
-        with ColmapDatabase.open_database(str(db_path)) as db_check:
-            num_imgs = ColmapDatabase.get_db_count(db_check, "num_images")
-            logger.info(f"Extracted features for {num_imgs} images")
+        from .. import dist as vd
 
+        if vd.is_distributed():
+            # one process per GPU (torchrun): images and pairs sharded, one descriptor all-gather, rank 0 writes (§8e)
+            from .distributed import run_sharded
+
+            if not hasattr(extractor, "_run_batch"):
+                raise NotImplementedError(f"{type(extractor).__name__} has no batched device path to shard")
+            logger.info("Extracting + matching on %d ranks...", vd.rank_world()[1])
+            if hasattr(extractor, "sync_projection"):
+                extractor.sync_projection(image_dir)      # the PCA / random projection is fitted once, on rank 0
+            self.last_stats = run_sharded(image_dir, db_path, camera_model, camera_params, feature_fn=extractor._run_batch,
+                                          matching_options=self.config.matching.to_matching_options(),
+                                          do_matching=self.config.do_matching, device=str(getattr(extractor, "device", "cuda")))
+            if vd.rank_world()[0] != 0:
+                return None
+        else:
+            logger.info("Extracting features...")
+            extractor.extract(image_dir, db_path, camera_model, camera_params)
+            with ColmapDatabase.open_database(str(db_path)) as db_check:
+                num_imgs = ColmapDatabase.get_db_count(db_check, "num_images")
+                logger.info(f"Extracted features for {num_imgs} images")
+
+            if self.config.do_matching:
+                from ..matching import match_exhaustive
+
+                logger.info("Running feature matching...")
+                opts = self.config.matching.to_matching_options()
+                self.last_stats = match_exhaustive(database_path=str(db_path), matching_options=opts)
         if self.config.do_matching:
-            from ..matching import match_exhaustive
-
-            logger.info("Running feature matching...")
-            opts = self.config.matching.to_matching_options()
-            self.last_stats = match_exhaustive(database_path=str(db_path), matching_options=opts)
             with ColmapDatabase.open_database(str(db_path)) as db_check:
                 num_pairs = ColmapDatabase.get_db_count(db_check, "num_matched_image_pairs")
-                logger.info(f"Matched {num_pairs} image pairs")
+                logger.info(f"Matched {num_pairs} image pairs ({db_check.num_verified_image_pairs()} geometrically verified)")
 
         reconstructions = None
         if self.config.do_reconstruction:
@@ -82,10 +100,27 @@ class Pipeline:
                 reconstructions = pycolmap.incremental_mapping(
                     database_path=str(db_path), image_path=str(image_dir), output_path=str(sparse_dir),
                     options=self.config.reconstruction.to_mapper_options())
-        if dataset and scene:
-            logger.info("metrics export is outside the accelerated path; the database at %s has the reference's "
-                        "schema and can be read by its MetricsExtractor", db_path)
+        if dataset and scene:                                   # run_pipeline.py:406-415
+            self.extract_and_export_metrics(db_path, output_dir, reconstructions, dataset, scene, results_dir)
         return reconstructions
+
+    def extract_and_export_metrics(self, db_path, output_dir, reconstructions, dataset, scene, results_dir=None):
+        """Database metrics -> `{results_dir}/{dataset}/{scene}/{extractor}.json` + summary.csv row
+        (reference run_pipeline.py:211-271; reconstruction metrics stay empty: the mapper is out of scope)."""
+        from ..utils.export import export_metrics, extract_all_metrics
+
+        try:
+            kind = self.config.extractor.extractor_type
+            kind = "sift" if kind == "colmap_sift" else kind
+            cfg = {"camera_model": self.config.camera.model, "min_num_matches": self.config.reconstruction.min_num_matches,
+                   "matching_max_ratio": self.config.matching.max_ratio, "matching_use_gpu": self.config.matching.use_gpu}
+            metrics = extract_all_metrics(db_path, dataset, scene, kind, cfg)
+            if results_dir:
+                export_metrics(metrics, Path(results_dir), formats=["json", "csv"])
+            return metrics
+        except Exception as e:  # noqa: BLE001 - reporting must never fail the run (run_pipeline.py:267-271)
+            logger.error(f"Failed to extract/export metrics: {e}")
+            return None
 
 
 def main() -> None:

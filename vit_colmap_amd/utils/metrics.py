@@ -7,9 +7,9 @@ Mirrors the database half of the reference's reporting — vit_colmap/utils/metr
 `two_view_geometries(pair_id, rows, config)`), over the standard library's sqlite3 only, so the reference's
 JSON / CSV reporting keeps working on databases written by this package.  Reconstruction metrics
 (metrics.py:270-, a pycolmap.Reconstruction walk) stay out of scope with the mapper.
-`two_view_geometries` is empty in databases produced here (geometric verification is outside the hot path):
-`verified_pairs`, the inlier statistics and `config_distribution` then read 0 / {} exactly as the reference's
-code does on an unverified database.
+`two_view_geometries` is written by matching/two_view.py (one row per matched pair, as COLMAP does [recalled]);
+on a database without that step `verified_pairs`, the inlier statistics and `config_distribution` read 0 / {}
+exactly as the reference's code does.
 """
 import json
 import sqlite3
