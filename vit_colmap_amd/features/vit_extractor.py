@@ -150,7 +150,7 @@ class ViTExtractor(BaseExtractor):
         B, h, w, _ = images_bgr.shape
         hp, wp = h // PATCH, w // PATCH
         if getattr(self.model, "_hip", None):
-            # ViT-S bf16: every GEMM of the forward is hand-written (csrc/gemm.hip); no hipBLASLt, no TunableOp
+            # ViT-S / B / L bf16: every GEMM of the forward is hand-written (csrc/gemm.hip); no hipBLASLt, no TunableOp
             patches = hip_preprocess.preprocess(images_bgr, out_dtype=self.dtype, layout="patches_pad")
             return self.model.forward_patch_tokens(patches, hp, wp).contiguous(), hp, wp
         patches = hip_preprocess.preprocess(images_bgr, out_dtype=self.dtype, layout="patches")

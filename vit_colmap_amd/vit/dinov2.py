@@ -16,8 +16,9 @@ MI355X-first choices
     (LN2+fc1+GELU+fc2+residual, the hidden tensor never leaves the chip) are hand-written bf16 MFMA kernels with fused
     prologues / epilogues, the attention a hand-written flash kernel — four kernels per block, no library GEMM and no
     standalone elementwise pass;
-  * other widths (`_blocks_fused`): `F.linear` (hipBLASLt) + the fused add+LayerNorm and attention kernels;
-    plain `nn.Module` path (`Block.forward`, SDPA) on the CPU / in float32 — the oracle-side evaluation;
+  * ViT-B / ViT-L (`_blocks_gemm`): the staged 128x128 MFMA GEMM (vc_linear_bf16) with bias / GELU / residual epilogues,
+    the LayerNorm and attention kernels — hand-written as well; only the SwiGLU giant (`_blocks_fused`) still uses
+    `F.linear`; plain `nn.Module` path (`Block.forward`, SDPA) on the CPU / in float32 — the oracle-side evaluation;
   * LayerScale is folded into the projection weights at load time, LayerNorm gamma / beta into the GEMM that
     follows (`prepare_hip`);
   * the forward is shape-static per batch size (no data-dependent control flow on the host).
@@ -251,14 +252,15 @@ class DinoV2(nn.Module):
         """Build the x-stationary GEMM operands (csrc/gemm.hip) of every block from the CURRENT parameters:
         qkv with norm1 folded in, proj, fc1 with norm2 folded in.  Call it while the parameters are still
         float32 (after fold_layerscale, on the GPU) so gamma is folded before the one rounding to bf16;
-        `_blocks_fused` calls it lazily otherwise.  Only the 384-wide MLP models (ViT-S) are covered."""
+        `_blocks_fused` calls it lazily otherwise.  ViT-S gets the x-stationary / fused-MLP operands, ViT-B / ViT-L bf16
+        weights for the staged GEMM (q rows pre-scaled); the SwiGLU giant is not covered (`_hip = False`)."""
         import os
 
         from .hip_ops import FusedMlp, XsLinear
         from .hip_ops import gelu_table as hip_ops_gelu_table
 
         self._hip = False
-        if self.arch.dim != 384 or self.arch.ffn != "mlp" or not all(b.folded for b in self.blocks):
+        if self.arch.ffn != "mlp" or self.arch.dim % 128 != 0 or not all(b.folded for b in self.blocks):
             return self
         if not self.pos_embed.is_cuda:
             raise RuntimeError("prepare_hip needs the model on the GPU")
@@ -266,6 +268,18 @@ class DinoV2(nn.Module):
         wp = torch.zeros(self.arch.dim, 640, dtype=torch.float32, device=w.device)
         wp[:, : w.shape[1]] = w
         self._pe_w = wp.to(torch.bfloat16).contiguous()          # conv weight as a [C][640] GEMM operand (zero padded K)
+        if self.arch.dim != 384:
+            # ViT-B / ViT-L: every Linear on the staged 128x128 MFMA kernel (csrc/gemm.hip, vc_linear_bf16) with bias /
+            # GELU / residual epilogues, the softmax scale folded into the q rows in float32 — no library GEMM either
+            bf = lambda t: t.detach().float().to(torch.bfloat16).contiguous()
+            self._hip = [dict(
+                kind="gemm",
+                qkv=tuple(bf(t) for t in _prescale_q(b.attn.qkv.weight, b.attn.qkv.bias, self.arch.dim)),
+                proj=(bf(b.attn.proj.weight), bf(b.attn.proj.bias)),
+                fc1=(bf(b.mlp.fc1.weight), bf(b.mlp.fc1.bias)),
+                fc2=(bf(b.mlp.fc2.weight), bf(b.mlp.fc2.bias)),
+            ) for b in self.blocks]
+            return self
         self._gelu_tab = hip_ops_gelu_table(w.device)
         self._use_fused_mlp = os.environ.get("VITCOLMAP_FUSED_MLP", "1") == "1"   # developer A/B switch: 0 = fc1 and fc2 as two kernels
         self._hip = [dict(
@@ -283,6 +297,8 @@ class DinoV2(nn.Module):
         x (B, 1 + T, C) incl. the class token -> normalised patch tokens (B, T, C), or all rows with drop_cls=False."""
         from . import hip_ops as ops
 
+        if self._hip and self._hip[0].get("kind") == "gemm":
+            return self._blocks_gemm(x, drop_cls)
         for blk, hw in zip(self.blocks, self._hip):
             a = ops.attention(hw["qkv"](x), blk.attn.num_heads, q_prescaled=True)   # LN1 + qkv (q pre-scaled), flash attention
             hw["proj"](a, ops.EPI_RESIDUAL, residual=x, out=x)            # x += proj(a)
@@ -293,6 +309,24 @@ class DinoV2(nn.Module):
             fc2 = blk.mlp.fc2
             ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=x, out=x)   # x += fc2(hdn)
         if drop_cls:   # final norm of the patch tokens only: the class-token row is dropped here, the caller gets a dense tensor
+            return ops.layernorm_drop_first(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return h
+
+    def _blocks_gemm(self, x, drop_cls: bool = True):
+        """ViT-B / ViT-L bf16 path: LayerNorm kernel + staged MFMA GEMMs with fused epilogues (bias; exact GELU; bias +
+        residual written in place on the residual stream) + the flash attention kernel; six launches per block, none of
+        them a library call.  x (B, 1 + T, C) -> normalised patch tokens (B, T, C), or all rows with drop_cls=False."""
+        from . import hip_ops as ops
+
+        for blk, hw in zip(self.blocks, self._hip):
+            _, h = ops.add_layernorm(x, None, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            a = ops.attention(ops.linear(h, *hw["qkv"]), blk.attn.num_heads, q_prescaled=True)
+            ops.linear(a, *hw["proj"], ops.EPI_RESIDUAL, residual=x, out=x)          # x += proj(a)
+            _, h = ops.add_layernorm(x, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            hdn = ops.linear(h, *hw["fc1"], ops.EPI_GELU)
+            ops.linear(hdn, *hw["fc2"], ops.EPI_RESIDUAL, residual=x, out=x)        # x += fc2(gelu(fc1(LN2 x)))
+        if drop_cls:
             return ops.layernorm_drop_first(x, self.norm.weight, self.norm.bias, self.norm.eps)
         _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
         return h
