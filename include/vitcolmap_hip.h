@@ -171,6 +171,20 @@ int vc_describe(const void* tokens, int token_dtype, int n_images, int H, int W,
                 int resized_w, int resized_h, int orig_w, int orig_h, float* out_kp,
                 float* out_desc_f32, uint8_t* out_desc_u8, vc_stream_t stream);
 
+/*
+ * Descriptors at GIVEN sub-pixel keypoints — replaces ViTExtractor._extract_descriptors_at_keypoints of the reference's
+ * hybrid extractor (vit_colmap/features/hybrid_extractor.py:224-294; the OpenCV detectors that produce the keypoints
+ * stay on the host).  keypoints_xy [n_images][kmax][2] float32 (x, y) in original-image pixels; the sampling position is
+ * x * (feat_w / orig_w) * (W / feat_w) as the reference computes it, then the same grid_sample arithmetic, optional
+ * projection and quantiser as vc_describe.  normalisation: VC_NORM_L2, or VC_NORM_ROOTSIFT = L1-normalise, sqrt(clamp(., 1e-8)),
+ * L2-normalise (:285-288).  out_desc_f32 may be NULL; rows >= count[i] are zero-filled.
+ */
+#define VC_NORM_L2 0
+#define VC_NORM_ROOTSIFT 1
+int vc_describe_at(const void* tokens, int token_dtype, int n_images, int H, int W, int C, const float* keypoints_xy,
+                   const int32_t* count, int kmax, const float* proj, int dd, int feat_w, int feat_h, int orig_w,
+                   int orig_h, int normalisation, float* out_desc_f32, uint8_t* out_desc_u8, vc_stream_t stream);
+
 /* The quantiser alone: out[i] = (uint8) clip(in[i] * 512, 0, 255)   (vit_extractor.py:250). */
 int vc_quantize_u8(const float* in, uint8_t* out, size_t n, vc_stream_t stream);
 

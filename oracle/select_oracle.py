@@ -240,6 +240,57 @@ def gather_descriptors(fmap: np.ndarray, coords: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(out.T.astype(F32))
 
 
+def sample_descriptors(fmap: np.ndarray, fy: np.ndarray, fx: np.ndarray) -> np.ndarray:
+    """`grid_sample(bilinear, border, align_corners=True)` at fractional grid coordinates (fy, fx) float32 — the
+    arithmetic of gather_descriptors without the integer assumption (hybrid_extractor.py:256-277)."""
+    C, H, W = fmap.shape
+    gy = F32(2.0) * fy.astype(F32) / F32(H - 1) - F32(1.0)
+    gx = F32(2.0) * fx.astype(F32) / F32(W - 1) - F32(1.0)
+    iy = np.clip(((gy + F32(1.0)) / F32(2.0)) * F32(H - 1), F32(0), F32(H - 1)).astype(F32)
+    ix = np.clip(((gx + F32(1.0)) / F32(2.0)) * F32(W - 1), F32(0), F32(W - 1)).astype(F32)
+    y0, x0 = np.floor(iy), np.floor(ix)
+    wy1, wx1 = (iy - y0).astype(F32), (ix - x0).astype(F32)
+    wy0, wx0 = (F32(1.0) - wy1).astype(F32), (F32(1.0) - wx1).astype(F32)
+    y0i, x0i = y0.astype(np.int64), x0.astype(np.int64)
+
+    def tap(yi, xi, w):
+        inside = (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W)
+        v = fmap[:, np.clip(yi, 0, H - 1), np.clip(xi, 0, W - 1)]
+        return np.where(inside[None, :], v, F32(0)) * w[None, :]
+
+    out = tap(y0i, x0i, wy0 * wx0) + tap(y0i, x0i + 1, wy0 * wx1) + tap(y0i + 1, x0i, wy1 * wx0) + tap(y0i + 1, x0i + 1, wy1 * wx1)
+    return np.ascontiguousarray(out.T.astype(F32))
+
+
+def rootsift_normalize(desc: np.ndarray) -> np.ndarray:
+    """hybrid_extractor.py:285-288: F.normalize(p=1) (eps 1e-12), sqrt(clamp(min=1e-8)), F.normalize(p=2)."""
+    d = desc.astype(F32)
+    l1 = np.maximum(np.abs(d).sum(axis=1, keepdims=True, dtype=F32), F32(1e-12))
+    d = np.sqrt(np.maximum(d / l1, F32(1e-8))).astype(F32)
+    return l2_normalize(d)
+
+
+def descriptors_at_keypoints(fmap, keypoints_xy, original_wh, feature_wh, descriptor_dim, projection=None):
+    """Reference hybrid extractor, `_extract_descriptors_at_keypoints` (hybrid_extractor.py:224-294):
+    keypoints (N, 2) float32 in original-image pixels -> (uint8 (N, D), float32 (N, D))."""
+    fmap = np.asarray(fmap, F32)
+    C, H, W = fmap.shape
+    kp = np.asarray(keypoints_xy, F32).reshape(-1, 2)
+    if len(kp) == 0:
+        return np.zeros((0, descriptor_dim), np.uint8), np.zeros((0, descriptor_dim), F32)
+    w_o, h_o = original_wh
+    w_f, h_f = feature_wh
+    fx = (kp[:, 0] * F32(w_f / w_o)) * F32(W / w_f)       # float32 array times Python doubles, one after the other
+    fy = (kp[:, 1] * F32(h_f / h_o)) * F32(H / h_f)
+    desc = sample_descriptors(fmap, fy, fx)
+    if desc.shape[1] > descriptor_dim:
+        if projection is None:
+            raise ValueError("projection matrix must be supplied (it is an input, not refit)")
+        desc = project(desc, projection)
+    desc = rootsift_normalize(desc)
+    return quantize_u8(desc), desc
+
+
 def map_keypoints(coords: np.ndarray, grid_hw, resized_wh, original_wh) -> np.ndarray:
     """vit_extractor.py:229-236 — (x + 0.5) * (w_resized / W) * (w_orig / w_resized), float32
     tensor times Python-double scalars applied one after the other; columns are (x, y)."""

@@ -47,6 +47,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vc_describe": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vc_describe_at": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                               c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vc_quantize_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "vc_heatmap_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vc_heatmap_keypoints": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int,

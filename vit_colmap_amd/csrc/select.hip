@@ -397,7 +397,11 @@ __global__ __launch_bounds__(256) void describe_kernel(const T* __restrict__ tok
                                                        const float* __restrict__ proj, int dd, float sx1,
                                                        float sx2, float sy1, float sy2,
                                                        float* __restrict__ out_kp, float* __restrict__ out_f32,
-                                                       uint8_t* __restrict__ out_u8) {
+                                                       uint8_t* __restrict__ out_u8,
+                                                       // hybrid extractor (hybrid_extractor.py:224-294): descriptors at given
+                                                       // sub-pixel keypoints (original-image pixels) instead of grid points,
+                                                       // RootSIFT normalisation instead of L2
+                                                       const float* __restrict__ kp_in, int rootsift) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -411,14 +415,26 @@ __global__ __launch_bounds__(256) void describe_kernel(const T* __restrict__ tok
   if (m >= n) {  // rows beyond the count are zero: the matcher reads whole blocks
     for (int j = lane; j < out_dim; j += 64) u8row[j] = 0;
     if (out_f32) for (int j = lane; j < out_dim; j += 64) out_f32[((size_t)img * kmax + m) * out_dim + j] = 0.f;
-    if (lane < 2) out_kp[((size_t)img * kmax + m) * 2 + lane] = 0.f;
+    if (out_kp && lane < 2) out_kp[((size_t)img * kmax + m) * 2 + lane] = 0.f;
     return;
   }
-  const int cy = yx[((size_t)img * kmax + m) * 2 + 0], cx = yx[((size_t)img * kmax + m) * 2 + 1];
-  // grid_sample(bilinear, border, align_corners=True) at the normalised integer coordinate,
+  int cy = 0, cx = 0;
+  float fy, fx;
+  if (kp_in) {
+    // kp * (w_feat / w_orig) * (W / w_feat): a float32 array times two Python doubles, one after the other
+    // (hybrid_extractor.py:249-254); sx1 / sx2 carry those factors here
+    fx = (kp_in[((size_t)img * kmax + m) * 2 + 0] * sx1) * sx2;
+    fy = (kp_in[((size_t)img * kmax + m) * 2 + 1] * sy1) * sy2;
+  } else {
+    cy = yx[((size_t)img * kmax + m) * 2 + 0];
+    cx = yx[((size_t)img * kmax + m) * 2 + 1];
+    fy = (float)cy;
+    fx = (float)cx;
+  }
+  // grid_sample(bilinear, border, align_corners=True) at the normalised coordinate,
   // with torch's float32 steps (oracle: gather_descriptors)
-  const float gy = 2.0f * (float)cy / (float)(H - 1) - 1.0f;
-  const float gx = 2.0f * (float)cx / (float)(W - 1) - 1.0f;
+  const float gy = 2.0f * fy / (float)(H - 1) - 1.0f;
+  const float gx = 2.0f * fx / (float)(W - 1) - 1.0f;
   float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
   float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
   iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
@@ -451,6 +467,15 @@ __global__ __launch_bounds__(256) void describe_kernel(const T* __restrict__ tok
     }
     d = o;
   }
+  float* dw = proj ? o : g;   // the wave's own copy, rewritten in place by the RootSIFT steps
+  if (rootsift) {
+    // hybrid_extractor.py:285-288: L1-normalise (eps 1e-12), sqrt(clamp(., 1e-8)), then the L2 step below
+    float s1 = 0.f;
+    for (int j = lane; j < out_dim; j += 64) s1 += fabsf(d[j]);
+    s1 = fmaxf(wave_sum(s1), 1e-12f);
+    for (int j = lane; j < out_dim; j += 64) dw[j] = sqrtf(fmaxf(d[j] / s1, 1e-8f));
+    d = dw;
+  }
   float ss = 0.f;
   for (int j = lane; j < out_dim; j += 64) ss += d[j] * d[j];
   ss = wave_sum(ss);
@@ -461,7 +486,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const T* __restrict__ tok
     const float q = fminf(fmaxf(v * 512.0f, 0.f), 255.f);
     u8row[j] = (uint8_t)q;  // truncation, negatives -> 0 (vit_extractor.py:250)
   }
-  if (lane == 0) {
+  if (out_kp && lane == 0) {
     out_kp[((size_t)img * kmax + m) * 2 + 0] = (((float)cx + 0.5f) * sx1) * sx2;
     out_kp[((size_t)img * kmax + m) * 2 + 1] = (((float)cy + 0.5f) * sy1) * sy2;
   }
@@ -575,11 +600,40 @@ int vc_describe(const void* tokens, int token_dtype, int n_images, int H, int W,
   const dim3 grid((kmax + 3) / 4, n_images);
   if (token_dtype == VC_DTYPE_F32)
     hipLaunchKernelGGL(describe_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, (const float*)tokens,
-                       H, W, C, yx, count, kmax, proj, dd, sx1, sx2, sy1, sy2, out_kp, out_desc_f32, out_desc_u8);
+                       H, W, C, yx, count, kmax, proj, dd, sx1, sx2, sy1, sy2, out_kp, out_desc_f32, out_desc_u8,
+                       (const float*)nullptr, 0);
   else
     hipLaunchKernelGGL(describe_kernel<uint16_t>, grid, dim3(256), smem, (hipStream_t)stream,
                        (const uint16_t*)tokens, H, W, C, yx, count, kmax, proj, dd, sx1, sx2, sy1, sy2, out_kp,
-                       out_desc_f32, out_desc_u8);
+                       out_desc_f32, out_desc_u8, (const float*)nullptr, 0);
+  return vc::check_launch();
+}
+
+int vc_describe_at(const void* tokens, int token_dtype, int n_images, int H, int W, int C, const float* keypoints_xy,
+                   const int32_t* count, int kmax, const float* proj, int dd, int feat_w, int feat_h, int orig_w,
+                   int orig_h, int normalisation, float* out_desc_f32, uint8_t* out_desc_u8, vc_stream_t stream) {
+  if (!tokens || !keypoints_xy || !count || !out_desc_u8) return VC_ERR_INVALID_ARG;
+  if (n_images < 0 || H <= 1 || W <= 1 || C <= 0 || kmax <= 0) return VC_ERR_INVALID_ARG;
+  if (token_dtype != VC_DTYPE_F32 && token_dtype != VC_DTYPE_BF16) return VC_ERR_INVALID_ARG;
+  if (proj && dd <= 0) return VC_ERR_INVALID_ARG;
+  if (normalisation != VC_NORM_L2 && normalisation != VC_NORM_ROOTSIFT) return VC_ERR_INVALID_ARG;
+  if (feat_w <= 0 || feat_h <= 0 || orig_w <= 0 || orig_h <= 0) return VC_ERR_INVALID_ARG;
+  if (n_images == 0) return VC_OK;
+  const int out_dim = proj ? dd : C;
+  const size_t smem = (size_t)4 * (C + out_dim) * sizeof(float);
+  if (smem > 64 * 1024) return VC_ERR_UNSUPPORTED;
+  // kp_x = x * (w_feat / w_orig) * (W / w_feat): two Python doubles applied in turn to a float32 array
+  const float sx1 = (float)((double)feat_w / (double)orig_w), sx2 = (float)((double)W / (double)feat_w);
+  const float sy1 = (float)((double)feat_h / (double)orig_h), sy2 = (float)((double)H / (double)feat_h);
+  const dim3 grid((kmax + 3) / 4, n_images);
+  if (token_dtype == VC_DTYPE_F32)
+    hipLaunchKernelGGL(describe_kernel<float>, grid, dim3(256), smem, (hipStream_t)stream, (const float*)tokens, H, W, C,
+                       (const int32_t*)nullptr, count, kmax, proj, dd, sx1, sx2, sy1, sy2, (float*)nullptr, out_desc_f32,
+                       out_desc_u8, keypoints_xy, normalisation == VC_NORM_ROOTSIFT ? 1 : 0);
+  else
+    hipLaunchKernelGGL(describe_kernel<uint16_t>, grid, dim3(256), smem, (hipStream_t)stream, (const uint16_t*)tokens, H, W,
+                       C, (const int32_t*)nullptr, count, kmax, proj, dd, sx1, sx2, sy1, sy2, (float*)nullptr, out_desc_f32,
+                       out_desc_u8, keypoints_xy, normalisation == VC_NORM_ROOTSIFT ? 1 : 0);
   return vc::check_launch();
 }
 

@@ -93,6 +93,29 @@ def describe(tokens: torch.Tensor, H: int, W: int, yx: torch.Tensor, count: torc
     return (kp, u8, f32) if want_f32 else (kp, u8)
 
 
+def describe_at(tokens: torch.Tensor, H: int, W: int, keypoints_xy: torch.Tensor, count: torch.Tensor, feature_wh, original_wh,
+                projection=None, rootsift: bool = True, want_f32: bool = False):
+    """Descriptors at given sub-pixel keypoints (reference hybrid_extractor.py:224-294): tokens (B, H*W, C),
+    keypoints_xy float32 (B, kmax, 2) in original-image pixels, count int32 (B,) -> uint8 (B, kmax, D)[, float32]."""
+    _check_tokens(tokens, H, W)
+    assert keypoints_xy.is_cuda and keypoints_xy.dtype == torch.float32 and keypoints_xy.is_contiguous() and keypoints_xy.shape[-1] == 2
+    lib = _lib.load()
+    B, _, C = tokens.shape
+    kmax = keypoints_xy.shape[1]
+    dd = 0
+    if projection is not None:
+        assert projection.is_cuda and projection.dtype == torch.float32 and projection.is_contiguous() and projection.shape[0] == C
+        dd = projection.shape[1]
+    D = dd if projection is not None else C
+    u8 = torch.empty((B, kmax, D), dtype=torch.uint8, device=tokens.device)
+    f32 = torch.empty((B, kmax, D), dtype=torch.float32, device=tokens.device) if want_f32 else None
+    _lib.check(lib.vc_describe_at(_lib.ptr(tokens), _dtype_code(tokens), B, H, W, C, _lib.ptr(keypoints_xy), _lib.ptr(count), kmax,
+                                  _lib.ptr(projection), dd, int(feature_wh[0]), int(feature_wh[1]), int(original_wh[0]),
+                                  int(original_wh[1]), 1 if rootsift else 0, _lib.ptr(f32), _lib.ptr(u8), _lib.stream_ptr()),
+               "vc_describe_at")
+    return (u8, f32) if want_f32 else u8
+
+
 def quantize_u8(x: torch.Tensor) -> torch.Tensor:
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
     lib = _lib.load()
