@@ -89,10 +89,43 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
   const int n_blk = (N + kKV - 1) / kKV;
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0][0][0]);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // Per-lane byte offsets of this wave's four pieces inside a block of 64 keys, computed ONCE: a block's source is then
+  // a wave-uniform base (SGPR pair, advanced by scalar instructions) plus these.  Computing the full 64-bit address per
+  // lane, piece and block cost ~250 issue cycles per block (v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate).
+  uint32_t voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pce = wave_u * 4 + i;
+    const int which = pce >> 3, kg = pce & 7;
+    const int krow = lane >> 3, cdst = lane & 7;
+    const int key = kg * 8 + krow;
+    const int csrc = which == 0 ? (cdst ^ krow) : (cdst ^ (((krow >> 1) & 1) << 2));
+    voff[i] = (uint32_t)(((size_t)key * tok_stride + (size_t)(1 + which) * H * kHD + csrc * 8) * sizeof(__bf16));
+  }
+  const size_t blk_bytes = (size_t)kKV * tok_stride * sizeof(__bf16);
   auto issue_block = [&](int blk, int slot) {
     blk = min(blk, n_blk - 1);   // past the end: re-stage the last block into a slot nobody reads
+    if ((blk + 1) * kKV <= N) {  // every key of the block exists: uniform base + precomputed offsets
+      const char* sbase = (const char*)base + (size_t)blk * blk_bytes;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i) {
+        const int pce = wave_u * 4 + i;
+        const uint32_t dst = lds0 + (uint32_t)slot * (2 * kTileBytes) + (uint32_t)(pce >> 3) * kTileBytes + (uint32_t)(pce & 7) * 1024u;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[i]), "s"(sbase), "s"(dst)
+            : "memory");
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // the ragged last block: keys past the end are clamped to the last token
       const int pce = wave_u * 4 + i;
       const int which = pce >> 3, kg = pce & 7;
       const int krow = lane >> 3, cdst = lane & 7;
@@ -147,7 +180,8 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       // LAZY: the running maximum of the lane's query (log2 units) is subtracted by the MFMA itself
-      const float c0 = (LAZY && blk > 0) ? -m_run[qt] : 0.f;
+      float c0 = (LAZY && blk > 0) ? -m_run[qt] : 0.f;
+      asm volatile("" : "+v"(c0));   // one select, then plain moves (left alone the compiler emits a v_cndmask per register)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -206,18 +240,18 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
           }
           l_run[qt] += lsum2[0] + lsum2[1];
 #else
-          float lsum = 0.f;
+          float lsum[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: an add never waits for its predecessor
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int t = s >> 1, r0 = 8 * (s & 1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float pj = __builtin_amdgcn_exp2f(acc_s[qt][t][r0 + j]);
-              lsum += pj;
+              lsum[j & 3] += pj;
               pf[qt][s][j] = (__bf16)pj;
             }
           }
-          l_run[qt] += lsum;
+          l_run[qt] += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
 #endif
           continue;
         }
