@@ -62,12 +62,16 @@ constexpr float kLazyTh = 6.0f;
 template <int QT, bool LAZY>
 __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const __bf16* __restrict__ qkv,
                                                                            __bf16* __restrict__ out, int N, int H,
-                                                                           float scale_log2e) {
+                                                                           float scale_log2e, int unit0, int nqb) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[3][2][kTileBytes];  // ring slot x [K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int q_row0 = blockIdx.x * (kQB * QT) + wave * (kQW * QT) + r;   // + 32*qt
+  // work unit = (batch * head, block of 128 QT query rows), numbered bh-major so that neighbouring workgroups share K / V
+  const int unit = unit0 + (int)blockIdx.x;
+  const int bh = unit / nqb, b = bh / H, h = bh - b * H;
+  const int q_base = (unit - bh * nqb) * (kQB * QT);
+  if (q_base >= N) return;   // (the second half of a ragged last block when the tail runs as 128-row units)
+  const int q_row0 = q_base + wave * (kQW * QT) + r;   // + 32*qt
   const size_t tok_stride = (size_t)3 * H * kHD;  // elements between consecutive tokens
   const __bf16* base = qkv + (size_t)b * N * tok_stride + (size_t)h * kHD;
 
@@ -353,13 +357,21 @@ int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int
   // two query tiles per wave once the sequence is long enough to fill the chip with 256-row blocks
   int qt = n_tokens >= 512 ? 2 : 1;
   if (const char* e = getenv("VITCOLMAP_ATTN_QT")) qt = atoi(e) == 1 ? 1 : 2;   // developer A/B switch
-  const dim3 grid((n_tokens + kQB * qt - 1) / (kQB * qt), batch * n_heads);
   const __bf16* pq = (const __bf16*)qkv;
   __bf16* po = (__bf16*)out;
   hipStream_t st = (hipStream_t)stream;
-#define VC_ATT(Q, L) hipLaunchKernelGGL((attention_kernel<Q, L>), grid, dim3(256), 0, st, pq, po, n_tokens, n_heads, scale_log2e)
-  if (qt == 1) { if (q_prescaled) VC_ATT(1, true); else VC_ATT(1, false); }
-  else { if (q_prescaled) VC_ATT(2, true); else VC_ATT(2, false); }
+  const int bh = batch * n_heads;
+#define VC_ATT(Q, L, UNITS, UNIT0, NQB) \
+  hipLaunchKernelGGL((attention_kernel<Q, L>), dim3(UNITS), dim3(256), 0, st, pq, po, n_tokens, n_heads, scale_log2e, UNIT0, NQB)
+  if (qt == 1) {
+    const int nqb = (n_tokens + kQB - 1) / kQB;
+    if (q_prescaled) VC_ATT(1, true, nqb * bh, 0, nqb); else VC_ATT(1, false, nqb * bh, 0, nqb);
+    return vc::check_launch();
+  }
+  // (Running the units of the last, partial "round" — 1800 units over 512 resident workgroups — as half-size QT = 1 units was
+  // measured: 241.5 vs 239.0 us, no gain; workgroups do not advance in lockstep rounds.  One launch.)
+  const int nqb2 = (n_tokens + 2 * kQB - 1) / (2 * kQB);
+  if (q_prescaled) VC_ATT(2, true, nqb2 * bh, 0, nqb2); else VC_ATT(2, false, nqb2 * bh, 0, nqb2);
 #undef VC_ATT
   return vc::check_launch();
 }
