@@ -39,9 +39,9 @@ def test_pure_host_entry_points():
     assert lib.vc_abi_version() == 1
     assert lib.vc_status_string(0) == b"ok"
     assert b"invalid" in lib.vc_status_string(-1)
-    # 50 images x 512 x 384: 16 tiles x 12 fragments x 1 KiB + 512 row sums
-    assert lib.vc_prepared_bytes(50, 512, 384) == 50 * (16 * 12 * 1024 + 512 * 4)
-    assert lib.vc_prepared_bytes(1, 300, 128) == 16 * 4 * 1024 + 512 * 4   # tiles round up to 16
+    # 50 images x 512 x 384: 16 tiles x 12 fragments x 1 KiB + 512 row sums + 512 head row sums + 16 tail norm bounds
+    assert lib.vc_prepared_bytes(50, 512, 384) == 50 * (16 * 12 * 1024 + 2 * 512 * 4 + 16 * 4)
+    assert lib.vc_prepared_bytes(1, 300, 128) == 16 * 4 * 1024 + 2 * 512 * 4 + 16 * 4   # tiles round up to 16
     assert lib.vc_prepared_bytes(1, 512, 4096) == 0       # beyond VC_MAX_DESC_DIM
     assert lib.vc_knn_workspace_bytes(512, 512, 384) > 2 * 196608
 

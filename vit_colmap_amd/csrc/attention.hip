@@ -59,6 +59,19 @@ __device__ inline uint32_t v_off(int key, int byte_in_row) {
 // float32 VALU work does not overlap with the matrix pipe on gfx950 (tools/overlap_probe.hip): removing one of the
 // five float issue slots per score is a direct saving.
 constexpr float kLazyTh = 6.0f;
+#ifdef VC_ATTN_STAMP
+// diagnostic build only (tools/stamp_attn.py): shader-clock totals per wave and phase, written over the wave's first output row
+__device__ __forceinline__ unsigned long long stamp_a() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define VC_AST(acc_) { const unsigned long long t_ = stamp_a(); acc_ += t_ - st_tp; st_tp = t_; }
+#else
+#define VC_AST(acc_)
+#endif
 template <int QT, bool LAZY>
 __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const __bf16* __restrict__ qkv,
                                                                            __bf16* __restrict__ out, int N, int H,
@@ -169,13 +182,20 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
   // columns 4p..4p+3 (p = i&3) of a 4-key x 16-d block
   const int grp = lane >> 4, gi = lane & 15, tq = gi >> 2, tp = gi & 3;
 
+#ifdef VC_ATTN_STAMP
+  unsigned long long st_wait = 0, st_dma = 0, st_qk = 0, st_sm = 0, st_pv = 0;
+  const unsigned long long st_t0 = stamp_a();
+  unsigned long long st_tp = st_t0;
+#endif
   int slot = 0;
   for (int blk = 0; blk < n_blk; ++blk) {
     // this wave's 4 pieces of block blk have landed when at most the 4 of block blk+1 are pending
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    VC_AST(st_wait)
     // the slot read in the previous iteration is free now: refill it two blocks ahead
     issue_block(blk + 2, slot == 0 ? 2 : slot - 1);
+    VC_AST(st_dma)
     const uint8_t* kt = lds[slot][0];
     const uint8_t* vt = lds[slot][1];
 
@@ -216,6 +236,7 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
           }
     }
 
+    VC_AST(st_qk)
     // ---- online softmax (exp2 domain); a lane and its partner (l ^ 32) share one query ------
     v8bf pf[QT][4];  // P^T as B operand: k-step s <- registers 8(s&1)..+7 of tile s>>1
 #pragma unroll
@@ -297,6 +318,7 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
       l_run[qt] += lsum;
     }
 
+    VC_AST(st_sm)
     // ---- O^T += V^T P^T : two 32-d tiles x four 16-key k-steps (each V fragment feeds QT MFMAs) --
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
@@ -318,8 +340,12 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
       }
     }
     slot = slot == 2 ? 0 : slot + 1;
+    VC_AST(st_pv)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two clamped refills before exiting
+#ifdef VC_ATTN_STAMP
+  const unsigned long long st_total = stamp_a() - st_t0;
+#endif
 
   // ---- normalise and store: lane (query r, half hh) holds d = (i&3) + 8(i>>2) + 4hh + 32dt -------
 #pragma unroll
@@ -340,6 +366,14 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
         }
     }
   }
+#ifdef VC_ATTN_STAMP
+  __syncthreads();   // after every wave's real stores: the wave's first output row now carries its stamps instead
+  if (lane == 0) {
+    uint32_t* dbg = (uint32_t*)(out + ((size_t)b * N + min(q_base + wave * (kQW * QT), N - 1)) * (size_t)H * kHD + (size_t)h * kHD);
+    dbg[0] = (uint32_t)st_wait; dbg[1] = (uint32_t)st_dma; dbg[2] = (uint32_t)st_qk; dbg[3] = (uint32_t)st_sm;
+    dbg[4] = (uint32_t)st_pv; dbg[5] = (uint32_t)st_total; dbg[6] = (uint32_t)n_blk; dbg[7] = 0x5354414du;
+  }
+#endif
 }
 
 }  // namespace

@@ -47,8 +47,13 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // neutral rows (all-zero descriptors: similarity 0 with everything).
 __host__ __device__ inline int tiles_of(int n_max) { return ceil_div(ceil_div(n_max, kTile), 16) * 16; }
 __host__ __device__ inline int ksteps_of(int d) { return ceil_div(d, 32); }
+// K steps in the "head" of a descriptor for the exact early-out of pair2_kernel (== ks: no early-out for that length)
+__host__ __device__ constexpr int head_steps_of(int ks) { return ks == 12 ? 8 : (ks == 8 ? 6 : ks); }
+// prepared image = fragments | row sums int32 [n_pad] | packed head / tail row sums int32 [n_pad] | per-tile tail norm bounds int32 [n_tiles]
+//   packed word   = (head << 15) | tail: sums of the row's bytes over the first head_steps_of(ks) * 32 dimensions and over the rest
+//   tail norm     = max over the tile's 32 rows of ceil(sqrt(sum of squared bytes over the remaining dimensions))
 __host__ __device__ inline size_t image_bytes(int n_tiles, int ks) {
-  return (size_t)n_tiles * ks * kFragBytes + (size_t)n_tiles * kTile * sizeof(int32_t);
+  return (size_t)n_tiles * ks * kFragBytes + (size_t)n_tiles * kTile * sizeof(int32_t) * 2 + (size_t)n_tiles * sizeof(int32_t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -148,13 +153,32 @@ __global__ void prepare_kernel(const uint8_t* __restrict__ desc, const int32_t* 
     }
     *(uint4*)(dst + (size_t)chunk * 16) = out;
   }
+  int32_t* rowsum_head = (int32_t*)(dst_img + (size_t)n_tiles * ks * kFragBytes) + (size_t)n_tiles * kTile + tile * kTile;
+  int32_t* tailnorm = (int32_t*)(dst_img + (size_t)n_tiles * ks * kFragBytes) + (size_t)2 * n_tiles * kTile + tile;
+  __shared__ int s_tn;
+  if (threadIdx.x == 0) s_tn = 0;
+  __syncthreads();
+  const int d_head = min(d, head_steps_of(ks) * 32);
   for (int c = threadIdx.x; c < kTile; c += blockDim.x) {
     const int row = tile * kTile + c;
-    int32_t sum = 0;
-    if (row < count)
-      for (int k = 0; k < d; ++k) sum += src[(size_t)row * d + k];
+    int32_t sum = 0, head = 0;
+    long long ss = 0;
+    if (row < count) {
+      for (int k = 0; k < d; ++k) {
+        const int v = src[(size_t)row * d + k];
+        sum += v;
+        if (k < d_head) head += v; else ss += v * v;
+      }
+    }
     rowsum[c] = sum;
+    // the early-out kernels read ONE word per row: head sum and tail sum packed (head <= 255 * 256 < 2^16, tail <= 255 * 128 < 2^15)
+    rowsum_head[c] = head_steps_of(ks) < ks ? ((head << 15) | (sum - head)) : head;
+    int tn = (int)ceil(sqrt((double)ss));
+    while ((long long)tn * tn < ss) ++tn;   // an upper bound of the Euclidean norm of the tail, whatever sqrt rounded to
+    atomicMax(&s_tn, tn);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) *tailnorm = s_tn;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -180,7 +204,9 @@ constexpr int kRowScratchBytes = kRowScratchEntries * 8;
 constexpr int kMaxSlots = 8;  // PF <= 7 keeps "one tile in flight per wave" true for 8 waves
 
 __host__ __device__ inline size_t lds_fixed_bytes(int n_pad) {
-  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + kWaves * kRowScratchBytes + 64;
+  // (+ head column terms [n_pad], tail norm bounds of b's tiles [n_pad / 32], tail row terms [waves][64]: pair2_kernel's early-out)
+  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + kWaves * kRowScratchBytes + 64 +
+         (size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4 + kWaves * 64 * 4 + (size_t)n_pad * 4 /* ColState padding */;
 }
 // number of ring slots for this problem size (0 = does not fit)
 inline int plan_slots(int ks, int n_pad) {
@@ -473,49 +499,80 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
 // MFMA phase with C = row term: acc[rt][4q + i] starts at rterm[32 rt + 8 q + 4 h + i] (the row that register
 // holds in the 32x32 MFMA C layout), read from the wave's LDS slice straight into the accumulator registers,
 // so the result is sum (a-128)(b-128) + 128 ra - 49024 D and the column term is all that is left to add.
-template <int KS, typename Mid>
-__device__ __forceinline__ void mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], const uint8_t* slot,
-                                            const int* rterm_wave, int lane, int h, Mid mid) {
+// Exact early-out (descriptors of 129..384 bytes: head_steps_of(KS) < KS), EARLY = true.  The accumulators start from the
+// HEAD row term and the first KH k-steps give, per element, s_head - (head column term).  The rest of the dot product is
+// bounded by Cauchy-Schwarz on the unbiased bytes: sum over the tail of a b <= |a_tail| |b_tail| <= TNa TNb (per-tile maxima
+// of the rounded-up tail norms, computed by prepare_kernel).  If no lane holds  acc > s_low - cth - TNa TNb  the whole 32x32
+// tile stays at or below the relevance threshold whatever the tail holds, so its remaining KS - KH MFMAs per row tile and
+// its epilogue are skipped: nothing it could contribute would change the match list (see relevance_threshold()).
+// Otherwise the tile is computed again from the full row term with all KS steps (the plain path) — the caller then stays on
+// the plain path until a tile turns out irrelevant again, so data on which the test keeps failing pays for it once.
+// Returns 3 if the wave's two row tiles were cut short (accumulators meaningless: the epilogue skips them), else 0.
+template <int KS, bool EARLY, typename Mid>
+__device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], const uint8_t* slot,
+                                           const int* rterm_wave, const int* rterm_head_wave, int lane, int h, int thr_early,
+                                           Mid mid) {
   constexpr int RT = 2;
-#ifdef VC2_G
-  constexpr int G = KS % VC2_G == 0 ? VC2_G : ((RT * KS >= 24) ? 2 : (KS < 4 ? KS : 4));
-#else
-  constexpr int G = (RT * KS >= 24) ? 2 : (KS < 4 ? KS : 4);
-#endif
+  constexpr int KH = head_steps_of(KS);
+  constexpr int G = (KS >= 8) ? 2 : (KS < 4 ? KS : 4);   // fragments per group (the head is a whole number of groups)
   constexpr int NG = KS / G;
-  static_assert(KS % G == 0, "KS must be a multiple of the fragment group");
+  constexpr int NGH = KH / G;                  // groups of the head
+  static_assert(KS % G == 0 && KH % G == 0, "KS and the head must be multiples of the fragment group");
   const uint8_t* src = slot + lane * 16;
 #ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(1);
 #endif
   v4i bf[2][G];
+  auto run = [&](const int* rterm, int n_groups, bool with_mid) {
 #pragma unroll
-  for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
+    for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4i cr = *(const v4i*)(rterm_wave + rt * kTile + 8 * q + 4 * h);
-      acc[rt][4 * q + 0] = cr[0]; acc[rt][4 * q + 1] = cr[1]; acc[rt][4 * q + 2] = cr[2]; acc[rt][4 * q + 3] = cr[3];
+      for (int q = 0; q < 4; ++q) {
+        const v4i cr = *(const v4i*)(rterm + rt * kTile + 8 * q + 4 * h);
+        acc[rt][4 * q + 0] = cr[0]; acc[rt][4 * q + 1] = cr[1]; acc[rt][4 * q + 2] = cr[2]; acc[rt][4 * q + 3] = cr[3];
+      }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g >= n_groups) break;
+      if (g + 1 < n_groups) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) bf[(g + 1) & 1][i] = *(const v4i*)(src + ((g + 1) * G + i) * kFragBytes);
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][g * G + i], bf[g & 1][i], acc[rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 0 && with_mid) mid();
     }
+  };
+  int cut = 0;
+  if (EARLY) {
+    run(rterm_head_wave, NGH, true);
+    // one test for both row tiles of the wave (threshold from the larger of their two tail bounds)
+    int m = max(acc[0][0], acc[1][0]);
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) {
-#pragma unroll
-      for (int i = 0; i < G; ++i) bf[(g + 1) & 1][i] = *(const v4i*)(src + ((g + 1) * G + i) * kFragBytes);
-    }
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][g * G + i], bf[g & 1][i], acc[rt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g == 0) mid();
+    for (int r = 1; r < 16; ++r) m = max(m, max(acc[0][r], acc[1][r]));
+    if (__any(m > thr_early)) run(rterm_wave, NG, false);   // may matter after all: the whole tile, plain
+    else cut = 3;
+  } else {
+    run(rterm_wave, NG, true);
   }
 #ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
+  return cut;
 }
+
+// per-column search state of pair2_kernel: one LDS address serves both atomics of the column merge
+struct ColState {
+  unsigned long long best;   // (s << 32) | ~row: highest s, lowest row on ties
+  u32 second;
+  u32 pad;
+};
 
 // Epilogue with the row term already inside the accumulators: s = acc + ct (ct: the lane's column term).
 //   relevance: some lane holds acc > s_low - ct                       (8 v_max3 + 1 compare per 32x32 tile)
@@ -524,8 +581,8 @@ __device__ __forceinline__ void mfma_phase2(const v4i (&afrag)[2][KS], v16i (&ac
 // `ct` is read from LDS by the caller BEFORE the MFMA phase that precedes this call: read here it queued behind
 // the other waves' fragment reads (stamps: ~450 of an epilogue's 660 cycles).  Column merge as in epilogue_phase.
 __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbest)[2][16], u32 (&rsec)[2][16],
-                                                int ct, unsigned long long* colbest, u32* colsecond,
-                                                int jt, int c, int h, u32 row_base, int s_low) {
+                                                int ct, ColState* col,
+                                                int jt, int c, int h, u32 row_base, int s_low, int cut) {
   constexpr int RT = 2;
   const int thr = s_low == 0x7fffffff ? s_low : s_low - ct;   // acc > thr  <=>  acc + ct > s_low (|ct| < 2^27: no overflow)
   const u32 ctj = ((u32)ct << 6) + (63u - (u32)jt);           // key = (acc << 6) + ctj   (acc + ct >= 0)
@@ -533,6 +590,7 @@ __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbes
   bool hit = false;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
+    if ((cut >> rt) & 1) continue;   // cut short by the early-out: proven irrelevant, accumulators incomplete
     int m = acc[rt][0];
 #pragma unroll
     for (int r = 1; r < 16; r += 2) m = max(m, r + 1 < 16 ? max(acc[rt][r], acc[rt][r + 1]) : acc[rt][r]);
@@ -560,10 +618,10 @@ __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbes
     const u32 sb = cb >> 6;
     const u32 grow = row_base + (63u - (cb & 63u)) + 4u * h;
     const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
-    const unsigned long long old = atomicMax(&colbest[j], key);
+    const unsigned long long old = atomicMax(&col[j].best, key);
     u32 cand = key > old ? (u32)(old >> 32) : sb;
     cand = umax(cand, cs2 >> 6);
-    atomicMax(&colsecond[j], cand);
+    atomicMax(&col[j].second, cand);
   }
   return hit;
 }
@@ -1114,15 +1172,25 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int n_pad = n_tiles_img * kTile;
   uint8_t* ring = smem;
-  unsigned long long* colbest = (unsigned long long*)(smem + (size_t)ns * KS * kFragBytes);
-  u32* colsecond = (u32*)(colbest + n_pad);
-  int* cterm = (int*)(colsecond + n_pad);
+  ColState* col = (ColState*)(smem + (size_t)ns * KS * kFragBytes);
+  int* cterm = (int*)(col + n_pad);
   int* m21 = cterm + n_pad;
   int* rbest_s = m21 + n_pad;
   int* rsecond_s = rbest_s + n_pad;
   int* ridx_s = rsecond_s + n_pad;
-  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D
+  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D (the HEAD part with the early-out)
   int* wave_count = crow6 + kWaves * 64 + kWaves * kRowScratchBytes / 4;
+  // early-out state (head_steps_of(KS) < KS): head column terms, tail norm bounds of b's tiles, tail row terms per wave
+  int* cterm_h = wave_count + 16;
+  int* tnb = cterm_h + n_pad;
+  int* crow6h = tnb + n_pad / kTile;        // [wave][RT*32]: HEAD row terms 128*ra_head - 49024*D_head
+  constexpr int KH = head_steps_of(KS);
+#ifdef VC2_NO_EARLY
+  constexpr bool kEarlyOut = false;
+#else
+  constexpr bool kEarlyOut = KH < KS;
+#endif
+  const int d_head = min(d, KH * 32);
 
 #ifdef VC_EXP_STAMP
   // diagnostic build: per-wave cycle totals over the workgroup's whole range (tools/stamp_matcher.py)
@@ -1139,6 +1207,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   const int c = lane & 31, h = lane >> 5;
   uint2* rscratch = (uint2*)(crow6 + kWaves * 64) + wave * kRowScratchEntries;  // this wave's slice
   int* crow6_wave = crow6 + wave * 64;
+  int* crow6h_wave = crow6h + wave * 64;
   const size_t img_stride = image_bytes(n_tiles_img, KS);
   const size_t frag_bytes_img = (size_t)n_tiles_img * KS * kFragBytes;
   const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
@@ -1186,7 +1255,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   for (int i = 0; i < pf; ++i) produce();
 
   int* pair_flag = wave_count + kWaves;   // "some tile of the current pair was relevant"
-  int rb_pref = tid < cur.n_ct * kTile ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[tid] : 0;
+  // with the early-out the per-row word is the packed (head << 15 | tail) sum, else the plain row sum
+  const int rs_off = kEarlyOut ? n_pad : 0;
+  int rb_pref = tid < cur.n_ct * kTile ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[rs_off + tid] : 0;
+  int tn_pref = (kEarlyOut && tid < cur.n_ct) ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[2 * n_pad + tid] : 0;
   // The two waves of a SIMD (w and w + 4) run half a tile apart, see pair_kernel.
 #ifdef VC2_NO_STAGGER
   constexpr bool late = false;
@@ -1195,6 +1267,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
 #endif
   v4i afrag[RT][KS];
   int cur_a = -1, cur_tile0 = -1;
+  int tna = 0;   // the larger tail norm bound of this wave's two row tiles (wave-uniform)
+  int early_score = 0, early_probe = 0;   // gate of the early-out (wave-uniform, kept across pairs)
   v16i acc[RT];   // (the late half's first epilogue of a pass looks at stale accumulators behind an unreachable threshold)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -1211,12 +1285,16 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     // ---- per-pair LDS state (the previous pair's finalisation ended with a barrier) ---------------------------
     // (columns 0..511 come from the register fetched during the previous pair: the load's latency was 2 k cycles
     // of every pair when it sat here)
-    if (tid < n_ct * kTile) { cterm[tid] = 128 * rb_pref + 32640 * d; colbest[tid] = 0ull; colsecond[tid] = 0u; }
-    for (int j = tid + kThreads; j < n_ct * kTile; j += kThreads) {
-      cterm[j] = 128 * b_rowsum[j] + 32640 * d;
-      colbest[j] = 0ull;
-      colsecond[j] = 0u;
-    }
+    auto init_column = [&](int j, int word) {
+      const int head = kEarlyOut ? (word >> 15) : 0, total = kEarlyOut ? head + (word & 0x7fff) : word;
+      cterm[j] = 128 * total + 32640 * d;
+      if (kEarlyOut) cterm_h[j] = 128 * head + 32640 * d_head;
+      col[j].best = 0ull;
+      col[j].second = 0u;
+    };
+    if (tid < n_ct * kTile) init_column(tid, rb_pref);
+    for (int j = tid + kThreads; j < n_ct * kTile; j += kThreads) init_column(j, b_rowsum[rs_off + j]);
+    if (kEarlyOut && tid < n_ct) tnb[tid] = tn_pref;   // (n_ct <= 64 tiles; fetched during the previous pair)
     for (int i = tid; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
     if (tid == 0) *pair_flag = 0;
     bool pair_hit = false;   // some tile of this wave held a relevant similarity
@@ -1231,7 +1309,15 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
             afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
         // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows); the slice is
         // wave-private and its LDS operations execute in order
-        crow6_wave[lane] = 128 * a_rowsum[tile0 * kTile + lane] - 49024 * d;
+        {
+          const int word = a_rowsum[rs_off + tile0 * kTile + lane];
+          const int head = kEarlyOut ? (word >> 15) : 0, total = kEarlyOut ? head + (word & 0x7fff) : word;
+          crow6_wave[lane] = 128 * total - 49024 * d;
+          if (kEarlyOut) {
+            crow6h_wave[lane] = 128 * head - 49024 * d_head;
+            tna = max(a_rowsum[2 * n_pad + tile0], a_rowsum[2 * n_pad + tile0 + 1]);
+          }
+        }
         cur_a = cur.a;
         cur_tile0 = tile0;
         // The fragments must have landed before the tile loop: left pending, the compiler's own wait counts for
@@ -1248,6 +1334,21 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       VC_ST(st_init)
 
       int ct = 0;   // column term of the tile whose epilogue comes next; always read ahead of an MFMA phase
+      int cut = 0;  // row tiles of that tile the early-out cut short (wave-uniform)
+      // thresholds of the early-out for column tile jt: acc_head > s_low - cth - TNa TNb  <=>  the tile may still matter
+      // When to try the early-out: a saturating score (+1 for a tile it cut short, -3 for a tile that had to be computed a
+      // second time in full) gates it, and while the score is negative one tile in 32 probes whether the data has changed.
+      // Non-matching data keeps it on; data on which the test fails half of the time or more pays ~1 % for the probes.
+      auto mfma_tile = [&](int jt, const uint8_t* slot) -> int {
+        if (kEarlyOut && s_low >= 0 && (early_score >= 0 || --early_probe <= 0)) {   // (s_low = -1: nothing may be skipped)
+          const int thr = s_low - cterm_h[jt * kTile + c] - __mul24(tna, tnb[jt]);
+          const int r = mfma_phase2<KS, true>(afrag, acc, slot, crow6_wave, crow6h_wave, lane, h, thr, produce);
+          if (r != 0) early_score = min(early_score + 1, 8);
+          else { early_score = max(early_score - 3, -8); early_probe = 32; }
+          return r;
+        }
+        return mfma_phase2<KS, false>(afrag, acc, slot, crow6_wave, crow6h_wave, lane, h, 0, produce);
+      };
       for (int jt = 0; jt < n_ct; ++jt) {
         wait_tile<KS>(wave, prod_seq - cons_seq - 1);
         wg_barrier();
@@ -1257,20 +1358,20 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         VC_ST(st_wait)
         if (!late) {
           ct = cterm[jt * kTile + c];
-          mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+          cut = mfma_tile(jt, slot);
           VC_ST(st_mfma)
         }
         const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
         const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, colbest, colsecond, ejt, c, h, row_base, eth);
+        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, c, h, row_base, eth, cut);
         VC_ST(st_epi)
         if (late) {
           ct = cterm[jt * kTile + c];
-          mfma_phase2<KS>(afrag, acc, slot, crow6_wave, lane, h, produce);
+          cut = mfma_tile(jt, slot);
           VC_ST(st_mfma)
         }
       }
-      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, colbest, colsecond, n_ct - 1, c, h, row_base, s_low);
+      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, n_ct - 1, c, h, row_base, s_low, cut);
       VC_ST(st_epi)
 
       // ---- row results of this pass (see pair_kernel) --------------------------------------------------------
@@ -1324,7 +1425,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     }  // passes
 
     // column sums of the next pair's image b (consumed by its LDS initialisation)
-    if (nxt.p < hi && tid < nxt.n_ct * kTile) rb_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[tid];
+    if (nxt.p < hi && tid < nxt.n_ct * kTile) rb_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[rs_off + tid];
+    if (kEarlyOut && nxt.p < hi && tid < nxt.n_ct) tn_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[2 * n_pad + tid];
     if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
     __syncthreads();
     if (*pair_flag == 0) {
@@ -1338,9 +1440,9 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     // ---- angle + ratio tests, cross check, ordered compaction ---------------------------------------------------
     if (cross_check) {
       for (int j = tid; j < n2; j += kThreads) {
-        const unsigned long long kb = colbest[j];
+        const unsigned long long kb = col[j].best;
         const int row = (int)(0xFFFFFFFFu - (u32)kb);
-        m21[j] = accept_tab((int)(kb >> 32), (int)colsecond[j], max_ratio, max_distance, s_low) ? row : -1;
+        m21[j] = accept_tab((int)(kb >> 32), (int)col[j].second, max_ratio, max_distance, s_low) ? row : -1;
       }
       __syncthreads();
     }
