@@ -292,7 +292,7 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             traffic_src = f"{TRAFFIC_PROFILE}: PMC passes of this command, not a measurement of this run"
         roof = {
-            "kernel": "pair_kernel (fused int8-MFMA similarity + row/column top-2 + ratio/cross-check)",
+            "kernel": "pair2_kernel<12> (persistent; fused int8-MFMA similarity + row/column top-2 + ratio/cross-check)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": round(launch_ms, 4), "launches_timed": n_launch, "pairs_per_launch": P,

@@ -112,6 +112,22 @@ def test_image_io_roundtrip_and_listing(tmp_path):
     assert [f.name for f in list_images(tmp_path)] == ["a.PNG", "b.png"]
 
 
+def test_image_io_pillow_fallback_applies_exif_orientation(tmp_path, monkeypatch):
+    """cv2.imread rotates by the EXIF orientation tag; the Pillow fallback has to do the same or keypoints of
+    portrait photos land in a transposed frame."""
+    PILImage = pytest.importorskip("PIL.Image")
+    rgb = np.zeros((4, 6, 3), np.uint8)
+    rgb[0, :, 0] = 255                                              # red top row
+    im = PILImage.fromarray(rgb)
+    exif = PILImage.Exif()
+    exif[0x0112] = 6                                                # "rotate 90 CW to display"
+    im.save(tmp_path / "r.png", exif=exif)                          # lossless: the colour test below is exact
+    monkeypatch.setattr(image_io, "_cv2", None)
+    back = image_io.imread(tmp_path / "r.png")
+    assert back.shape == (6, 4, 3)                                  # rotated: 6 rows, 4 columns
+    assert back[:, -1, 2].min() > 200 and back[:, 0, 2].max() < 60  # the red row is now the right column (BGR: channel 2)
+
+
 def test_dummy_extractor_contract(tmp_path):
     assert issubclass(DummyExtractor, BaseExtractor)
     d = tmp_path / "images"
