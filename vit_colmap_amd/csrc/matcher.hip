@@ -48,7 +48,7 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 __host__ __device__ inline int tiles_of(int n_max) { return ceil_div(ceil_div(n_max, kTile), 16) * 16; }
 __host__ __device__ inline int ksteps_of(int d) { return ceil_div(d, 32); }
 // K steps in the "head" of a descriptor for the exact early-out of pair2_kernel (== ks: no early-out for that length)
-__host__ __device__ constexpr int head_steps_of(int ks) { return ks == 12 ? 8 : (ks == 8 ? 6 : ks); }
+__host__ __device__ constexpr int head_steps_of(int ks) { return ks == 12 ? 8 : (ks == 8 ? 4 : ks); }   // multiples of BWindow::NB
 // prepared image = fragments | row sums int32 [n_pad] | packed head / tail row sums int32 [n_pad] | per-tile tail norm bounds int32 [n_tiles]
 //   packed word   = (head << 15) | tail: sums of the row's bytes over the first head_steps_of(ks) * 32 dimensions and over the rest
 //   tail norm     = max over the tile's 32 rows of ceil(sqrt(sum of squared bytes over the remaining dimensions))
@@ -277,20 +277,22 @@ __device__ __forceinline__ u32 lds_addr(const void* p) {
 // each (KS = 12: waves 0..5 issue 2 pieces per tile), so no wave is held up for a whole tile's
 // worth of LDS-DMA issue.  Every producer wave has the same number of pieces in flight per tile,
 // which makes "my pieces of tile t have landed" a counted wait: vmcnt(M * tiles issued after t).
-template <int KS>
+// PW: the waves that may produce (pair2_kernel: the four EARLY waves only — they wait at the barrier for the late half
+// anyway, so neither the issue of the pieces nor the wait for them to land sits on the late waves' critical path).
+template <int KS, int PW = kWaves>
 struct Producer {
-  static constexpr int M = (KS + kWaves - 1) / kWaves;
+  static constexpr int M = (KS + PW - 1) / PW;
   static constexpr int NP = KS / M;
-  static_assert(NP * M == KS && NP <= kWaves, "pieces must divide evenly over the producer waves");
+  static_assert(NP * M == KS && NP <= PW, "pieces must divide evenly over the producer waves");
 };
 
-template <int KS>
+template <int KS, int PW = kWaves>
 __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ tile_src, u32 slot_lds, int wave, int lane) {
-  constexpr int M = Producer<KS>::M;
+  constexpr int M = Producer<KS, PW>::M;
 #ifdef VC_EXP_NO_STAGE
   return;
 #endif
-  if (wave < Producer<KS>::NP) {
+  if (wave < Producer<KS, PW>::NP) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int kk = wave * M + m;
@@ -301,10 +303,13 @@ __device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ tile_src,
 
 // Wait until this wave's pieces of the oldest tile in flight have landed; `younger` tiles
 // (0..7) were issued after it.  s_waitcnt takes an immediate, hence the switch.
-template <int KS>
+template <int KS, int PW = kWaves>
 __device__ __forceinline__ void wait_tile(int wave, int younger) {
-  constexpr int M = Producer<KS>::M;
-  if (wave < Producer<KS>::NP) {
+  constexpr int M = Producer<KS, PW>::M;
+#ifdef VC_EXP_NO_WAIT
+  return;   // timing experiment only (results are wrong)
+#endif
+  if (wave < Producer<KS, PW>::NP) {
 #define VC_W(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * M) : "memory")
     // binary decision tree: three scalar branches per call instead of a chain of eight
     if (younger < 4) {
@@ -508,24 +513,55 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
 // Otherwise the tile is computed again from the full row term with all KS steps (the plain path) — the caller then stays on
 // the plain path until a tile turns out irrelevant again, so data on which the test keeps failing pays for it once.
 // Returns 3 if the wave's two row tiles were cut short (accumulators meaningless: the epilogue skips them), else 0.
+// B operands come through a rolling window of NB fragment registers, D = NB - 1 k-steps ahead of the MFMAs that use them
+// (stamps: with one two-fragment group of look-ahead a wave alone on the pipe ran its 24 MFMAs in ~1300 cycles instead
+// of 768 — every group waited for an LDS read issued 128 pipe cycles earlier).  The window does not stop at the end of the
+// tile: the last D steps fetch fragments 0..D-1 of the NEXT tile of the ring (into bf[0..D-1], KS and the head being
+// multiples of NB), so the next phase starts with its first operands in registers.  That needs the next tile published
+// by the barrier in front of this one: the caller waits one tile further ahead and passes primed = false when the
+// tile was not in flight yet (tiny images, the very first tile) — then the window is filled here, latency exposed.
+template <int KS>
+struct BWindow {
+  static constexpr int NB = KS >= 4 ? 4 : KS;
+  static constexpr int D = NB - 1;
+  static_assert(KS % NB == 0 && head_steps_of(KS) % NB == 0, "window positions must repeat from tile to tile");
+};
+
+template <int KS, int N, typename Mid>
+__device__ __forceinline__ void mfma_steps(const v4i (&afrag)[2][KS], v16i (&acc)[2], v4i (&bf)[BWindow<KS>::NB],
+                                           const uint8_t* src, const uint8_t* nsrc, bool with_mid, Mid mid) {
+  constexpr int NB = BWindow<KS>::NB, D = BWindow<KS>::D;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int f = k + D;
+    if (NB > 1) bf[f % NB] = *(const v4i*)(f < N ? src + f * kFragBytes : nsrc + (f - N) * kFragBytes);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][k], bf[k % NB], acc[rt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NB == 1) bf[0] = *(const v4i*)(k + 1 < N ? src + (k + 1) * kFragBytes : nsrc);
+    if (k == 0 && with_mid) mid();
+  }
+}
+
 template <int KS, bool EARLY, typename Mid>
-__device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], const uint8_t* slot,
+__device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], v4i (&bf)[BWindow<KS>::NB],
+                                           const uint8_t* slot, const uint8_t* next_slot, bool primed,
                                            const int* rterm_wave, const int* rterm_head_wave, int lane, int h, int thr_early,
                                            Mid mid) {
   constexpr int RT = 2;
   constexpr int KH = head_steps_of(KS);
-  constexpr int G = (KS >= 8) ? 2 : (KS < 4 ? KS : 4);   // fragments per group (the head is a whole number of groups)
-  constexpr int NG = KS / G;
-  constexpr int NGH = KH / G;                  // groups of the head
-  static_assert(KS % G == 0 && KH % G == 0, "KS and the head must be multiples of the fragment group");
+  constexpr int NB = BWindow<KS>::NB, D = BWindow<KS>::D;
   const uint8_t* src = slot + lane * 16;
+  const uint8_t* nsrc = next_slot + lane * 16;
 #ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(1);
 #endif
-  v4i bf[2][G];
-  auto run = [&](const int* rterm, int n_groups, bool with_mid) {
+  auto fill = [&]() {
 #pragma unroll
-    for (int i = 0; i < G; ++i) bf[0][i] = *(const v4i*)(src + i * kFragBytes);
+    for (int i = 0; i < (NB > 1 ? D : 1); ++i) bf[i] = *(const v4i*)(src + i * kFragBytes);
+  };
+  auto init = [&](const int* rterm) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -533,33 +569,26 @@ __device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc
         const v4i cr = *(const v4i*)(rterm + rt * kTile + 8 * q + 4 * h);
         acc[rt][4 * q + 0] = cr[0]; acc[rt][4 * q + 1] = cr[1]; acc[rt][4 * q + 2] = cr[2]; acc[rt][4 * q + 3] = cr[3];
       }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g >= n_groups) break;
-      if (g + 1 < n_groups) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) bf[(g + 1) & 1][i] = *(const v4i*)(src + ((g + 1) * G + i) * kFragBytes);
-      }
-#pragma unroll
-      for (int i = 0; i < G; ++i)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][g * G + i], bf[g & 1][i], acc[rt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g == 0 && with_mid) mid();
-    }
   };
+  if (!primed) fill();   // wave-uniform
   int cut = 0;
   if (EARLY) {
-    run(rterm_head_wave, NGH, true);
+    init(rterm_head_wave);
+    mfma_steps<KS, KH>(afrag, acc, bf, src, nsrc, true, mid);   // (its last steps fetch the next tile: a cut is the common case)
     // one test for both row tiles of the wave (threshold from the larger of their two tail bounds)
     int m = max(acc[0][0], acc[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = max(m, max(acc[0][r], acc[1][r]));
-    if (__any(m > thr_early)) run(rterm_wave, NG, false);   // may matter after all: the whole tile, plain
-    else cut = 3;
+    if (__any(m > thr_early)) {   // may matter after all: the whole tile, plain
+      fill();
+      init(rterm_wave);
+      mfma_steps<KS, KS>(afrag, acc, bf, src, nsrc, false, mid);
+    } else {
+      cut = 3;
+    }
   } else {
-    run(rterm_wave, NG, true);
+    init(rterm_wave);
+    mfma_steps<KS, KS>(afrag, acc, bf, src, nsrc, true, mid);
   }
 #ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(0);
@@ -580,9 +609,14 @@ struct ColState {
 // The relevance test is cheap enough to run on every tile, so there is no separate "dense" regime here.
 // `ct` is read from LDS by the caller BEFORE the MFMA phase that precedes this call: read here it queued behind
 // the other waves' fragment reads (stamps: ~450 of an epilogue's 660 cycles).  Column merge as in epilogue_phase.
+// The update path wants ~30 temporaries: the B window (fetched ahead for the next tile, see mfma_phase2) is given up
+// there — `drop_window()` ends its registers' lifetime and tells the caller to refill — so that tiles without a relevant
+// entry keep the window and tiles with one do not spill (a spill reload in the tile loop makes the compiler wait for
+// vmcnt, which drains the LDS-DMA ring).
+template <typename Drop>
 __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbest)[2][16], u32 (&rsec)[2][16],
                                                 int ct, ColState* col,
-                                                int jt, int c, int h, u32 row_base, int s_low, int cut) {
+                                                int jt, int c, int h, u32 row_base, int s_low, int cut, Drop drop_window) {
   constexpr int RT = 2;
   const int thr = s_low == 0x7fffffff ? s_low : s_low - ct;   // acc > thr  <=>  acc + ct > s_low (|ct| < 2^27: no overflow)
   const u32 ctj = ((u32)ct << 6) + (63u - (u32)jt);           // key = (acc << 6) + ctj   (acc + ct >= 0)
@@ -596,6 +630,7 @@ __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbes
     for (int r = 1; r < 16; r += 2) m = max(m, r + 1 < 16 ? max(acc[rt][r], acc[rt][r + 1]) : acc[rt][r]);
     if (__any(m > thr)) {
       hit = true;
+      drop_window();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const u32 rk = ((u32)acc[rt][r] << 6) + ctj;
@@ -1162,6 +1197,11 @@ __device__ __forceinline__ PairInfo next_pair_with_work(int p, int hi, const int
   return r;
 }
 
+#ifdef VC2_ALL_PRODUCE
+constexpr int kProd2 = kWaves;
+#else
+constexpr int kProd2 = kWaves / 2;   // LDS-DMA pieces are issued by the early half (waves 0..3)
+#endif
 template <int KS>
 __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
@@ -1201,6 +1241,14 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
 #else
 #define VC_ST(acc_)
 #endif
+#ifdef VC_EXP_TRACE
+  // diagnostic build (with VC_EXP_STAMP, data without matches): per column tile and wave eight words
+  // {barrier arrival, release, MFMA begin, MFMA end, epilogue end, cut, -, -} into the workgroup's own (empty) match blocks
+  int trace_i = 0;
+#define VC_TR(k_, v_) { if ((threadIdx.x & 63) == 0 && trace_i >= 16 && trace_i < trace_n) trace[((size_t)trace_i * 8 + wave) * 8 + (k_)] = (uint32_t)(v_); }
+#else
+#define VC_TR(k_, v_)
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1223,6 +1271,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     for (int q = lo; q < cur.p && q < hi; ++q) out_counts[q] = 0;   // empty images: nothing can match
   if (cur.p >= hi) return;
   PairInfo nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride);
+#ifdef VC_EXP_TRACE
+  uint32_t* trace = out_matches + (size_t)lo * n_max * 2;
+  const int trace_n = (int)(((size_t)(hi - lo) * n_max * 2) / 64);
+#endif
 
   // ---- producer: a stream of column tiles over (pair, pass, tile), PF tiles ahead of the consumer ----------
   // It sweeps the current pair's image b once per row pass, then moves on to the NEXT pair (whose description is
@@ -1236,7 +1288,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int prod_seq = 0, prod_slot = 0, cons_seq = 0, cons_slot = 0;
   auto produce = [&]() {
     if (p_active) {
-      stage_tile<KS>(p_src, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
+      stage_tile<KS, kProd2>(p_src, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
       ++prod_seq;
       if (++prod_slot == ns) prod_slot = 0;
       p_src += KS * kFragBytes;
@@ -1269,6 +1321,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int cur_a = -1, cur_tile0 = -1;
   int tna = 0;   // the larger tail norm bound of this wave's two row tiles (wave-uniform)
   int early_score = 0, early_probe = 0;   // gate of the early-out (wave-uniform, kept across pairs)
+  v4i bf[BWindow<KS>::NB];   // the B operand window, carried from tile to tile (mfma_phase2)
+#pragma unroll
+  for (int i = 0; i < BWindow<KS>::NB; ++i) bf[i] = v4i{0, 0, 0, 0};
+  bool primed = false;       // bf holds the first fragments of the tile about to be consumed (wave-uniform)
   v16i acc[RT];   // (the late half's first epilogue of a pass looks at stale accumulators behind an unreachable threshold)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -1292,11 +1348,16 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       col[j].best = 0ull;
       col[j].second = 0u;
     };
-    if (tid < n_ct * kTile) init_column(tid, rb_pref);
-    for (int j = tid + kThreads; j < n_ct * kTile; j += kThreads) init_column(j, b_rowsum[rs_off + j]);
-    if (kEarlyOut && tid < n_ct) tnb[tid] = tn_pref;   // (n_ct <= 64 tiles; fetched during the previous pair)
-    for (int i = tid; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
-    if (tid == 0) *pair_flag = 0;
+    // Per-pair code indexes through a laundered copy of the thread id: with `tid` itself the compiler keeps a dozen
+    // LDS / global addresses alive across the tile loop, spills them, and every reload costs an s_waitcnt vmcnt that
+    // drains the LDS-DMA ring (the compiler cannot see the copies in flight).  A few more VALU instructions per pair.
+    int tidp = tid;
+    asm volatile("" : "+v"(tidp));
+    if (tidp < n_ct * kTile) init_column(tidp, rb_pref);
+    for (int j = tidp + kThreads; j < n_ct * kTile; j += kThreads) init_column(j, b_rowsum[rs_off + j]);
+    if (kEarlyOut && tidp < n_ct) tnb[tidp] = tn_pref;   // (n_ct <= 64 tiles; fetched during the previous pair)
+    for (int i = tidp; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
+    if (tidp == 0) *pair_flag = 0;
     bool pair_hit = false;   // some tile of this wave held a relevant similarity
 
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -1339,39 +1400,77 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       // When to try the early-out: a saturating score (+1 for a tile it cut short, -3 for a tile that had to be computed a
       // second time in full) gates it, and while the score is negative one tile in 32 probes whether the data has changed.
       // Non-matching data keeps it on; data on which the test fails half of the time or more pays ~1 % for the probes.
+      bool primed_next = false;
+      const uint8_t* next_slot = ring;
+      auto drop_window = [&]() {
+#pragma unroll
+        for (int i = 0; i < BWindow<KS>::NB; ++i) asm volatile("" : "=v"(bf[i]));   // (no instruction: the old values die here)
+        primed = false;
+      };
       auto mfma_tile = [&](int jt, const uint8_t* slot) -> int {
+        const bool have = primed;
+        primed = primed_next;
         if (kEarlyOut && s_low >= 0 && (early_score >= 0 || --early_probe <= 0)) {   // (s_low = -1: nothing may be skipped)
           const int thr = s_low - cterm_h[jt * kTile + c] - __mul24(tna, tnb[jt]);
-          const int r = mfma_phase2<KS, true>(afrag, acc, slot, crow6_wave, crow6h_wave, lane, h, thr, produce);
+          const int r = mfma_phase2<KS, true>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, h, thr, produce);
           if (r != 0) early_score = min(early_score + 1, 8);
           else { early_score = max(early_score - 3, -8); early_probe = 32; }
           return r;
         }
-        return mfma_phase2<KS, false>(afrag, acc, slot, crow6_wave, crow6h_wave, lane, h, 0, produce);
+        return mfma_phase2<KS, false>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, h, 0, produce);
       };
       for (int jt = 0; jt < n_ct; ++jt) {
-        wait_tile<KS>(wave, prod_seq - cons_seq - 1);
+        VC_TR(0, st_tp)
+        // The barrier publishes this tile AND the next one of the ring (if it is in flight): the MFMA phase ends by
+        // fetching the next tile's first fragments.
+        const int lead = prod_seq - cons_seq;          // tiles staged and not yet consumed, this one included
+#ifdef VC2_XTILE
+        // (experiment: the window runs on into the next tile.  It needs 12 more live registers across the epilogue; the
+        // build spills, and a spill reload anywhere near this loop makes the compiler wait for vmcnt, which drains the
+        // LDS-DMA ring — 11.6 M pairs/s against 13.2 M.  Off until the registers are found.)
+        wait_tile<KS, kProd2>(wave, lead >= 2 ? lead - 2 : 0);
         wg_barrier();
+        primed_next = lead >= 2;
+#else
+        wait_tile<KS, kProd2>(wave, lead - 1);
+#ifdef VC_EXP_TRACE
+        VC_TR(6, stamp())
+#endif
+        wg_barrier();
+        primed_next = false;
+#endif
         const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
         if (++cons_slot == ns) cons_slot = 0;
+        next_slot = ring + (size_t)cons_slot * KS * kFragBytes;
         ++cons_seq;
         VC_ST(st_wait)
+        VC_TR(1, st_tp)
         if (!late) {
+          VC_TR(2, st_tp)
           ct = cterm[jt * kTile + c];
           cut = mfma_tile(jt, slot);
           VC_ST(st_mfma)
+          VC_TR(3, st_tp)
+          VC_TR(5, cut)
         }
         const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
         const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, c, h, row_base, eth, cut);
+        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, c, h, row_base, eth, cut, drop_window);
         VC_ST(st_epi)
+        VC_TR(4, st_tp)
         if (late) {
+          VC_TR(2, st_tp)
           ct = cterm[jt * kTile + c];
           cut = mfma_tile(jt, slot);
           VC_ST(st_mfma)
+          VC_TR(3, st_tp)
+          VC_TR(5, cut)
         }
+#ifdef VC_EXP_TRACE
+        ++trace_i;
+#endif
       }
-      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, n_ct - 1, c, h, row_base, s_low, cut);
+      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, n_ct - 1, c, h, row_base, s_low, cut, drop_window);
       VC_ST(st_epi)
 
       // ---- row results of this pass (see pair_kernel) --------------------------------------------------------
@@ -1425,21 +1524,25 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     }  // passes
 
     // column sums of the next pair's image b (consumed by its LDS initialisation)
-    if (nxt.p < hi && tid < nxt.n_ct * kTile) rb_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[rs_off + tid];
-    if (kEarlyOut && nxt.p < hi && tid < nxt.n_ct) tn_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[2 * n_pad + tid];
+    int tidf = tid;   // (as tidp: the finalisation's addresses are computed here, not carried through the tile loop)
+    asm volatile("" : "+v"(tidf));
+#ifndef VC_EXP_NO_COLSUM
+    if (nxt.p < hi && tidf < nxt.n_ct * kTile) rb_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[rs_off + tidf];
+    if (kEarlyOut && nxt.p < hi && tidf < nxt.n_ct) tn_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[2 * n_pad + tidf];
+#endif
     if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
     __syncthreads();
     if (*pair_flag == 0) {
       // No tile of the pair held a similarity above the relevance threshold: every row's best stays below what the
       // angle test accepts, the match list is empty and nothing of the finalisation has to run.
-      if (tid == 0) {
+      if (tidf == 0) {
         out_counts[p] = 0;
         for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;
       }
     } else {
     // ---- angle + ratio tests, cross check, ordered compaction ---------------------------------------------------
     if (cross_check) {
-      for (int j = tid; j < n2; j += kThreads) {
+      for (int j = tidf; j < n2; j += kThreads) {
         const unsigned long long kb = col[j].best;
         const int row = (int)(0xFFFFFFFFu - (u32)kb);
         m21[j] = accept_tab((int)(kb >> 32), (int)col[j].second, max_ratio, max_distance, s_low) ? row : -1;
@@ -1449,7 +1552,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     uint32_t* out = out_matches + (size_t)p * n_max * 2;
     int base = 0;
     for (int i0 = 0; i0 < n1; i0 += kThreads) {
-      const int i = i0 + tid;
+      const int i = i0 + tidf;
       bool ok = false;
       int j = -1;
       if (i < n1) {
@@ -1475,7 +1578,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       base += chunk_total;
       __syncthreads();
     }
-    if (tid == 0) {
+    if (tidf == 0) {
       out_counts[p] = base;
       for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;   // empty images between this pair and the next
     }
@@ -1503,6 +1606,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   }
 #endif
 #undef VC_ST
+#undef VC_TR
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1745,6 +1849,14 @@ __global__ __launch_bounds__(kT3, 1) void pair3_kernel(
 #define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - st_tp; st_tp = t_; }
 #else
 #define VC_ST(acc_)
+#endif
+#ifdef VC_EXP_TRACE
+  // diagnostic build (with VC_EXP_STAMP, data without matches): per column tile and wave eight words
+  // {barrier arrival, release, MFMA begin, MFMA end, epilogue end, cut, -, -} into the workgroup's own (empty) match blocks
+  int trace_i = 0;
+#define VC_TR(k_, v_) { if ((threadIdx.x & 63) == 0 && trace_i >= 16 && trace_i < trace_n) trace[((size_t)trace_i * 8 + wave) * 8 + (k_)] = (uint32_t)(v_); }
+#else
+#define VC_TR(k_, v_)
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -2036,6 +2148,7 @@ __global__ __launch_bounds__(kT3, 1) void pair3_kernel(
   }
 #endif
 #undef VC_ST
+#undef VC_TR
 }
 
 #endif  // VC_PAIR3_EXPERIMENT
