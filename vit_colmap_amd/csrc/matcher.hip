@@ -202,11 +202,14 @@ constexpr int kLdsBytes = 160 * 1024;
 constexpr int kRowScratchEntries = 16 * 33;
 constexpr int kRowScratchBytes = kRowScratchEntries * 8;
 constexpr int kMaxSlots = 8;  // PF <= 7 keeps "one tile in flight per wave" true for 8 waves
+constexpr int kPairWindow = 64;   // pair2_kernel: pairs-with-work described in LDS at a time (one wave builds the list)
 
 __host__ __device__ inline size_t lds_fixed_bytes(int n_pad) {
   // (+ head column terms [n_pad], tail norm bounds of b's tiles [n_pad / 32], tail row terms [waves][64]: pair2_kernel's early-out)
+  // (+ pair2_kernel: two buffers of image b's column sums / tile bounds filled by LDS-DMA one pair ahead, the pair window)
   return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + kWaves * kRowScratchBytes + 64 +
-         (size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4 + kWaves * 64 * 4 + (size_t)n_pad * 4 /* ColState padding */;
+         (size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4 + kWaves * 64 * 4 + (size_t)n_pad * 4 /* ColState padding */ +
+         2 * ((size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4) + kPairWindow * 16 + 16;
 }
 // number of ring slots for this problem size (0 = does not fit)
 inline int plan_slots(int ks, int n_pad) {
@@ -263,6 +266,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst_any) {
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// One 256-byte LDS-DMA piece (64 lanes x 4 B; inactive lanes copy nothing): LDS destination = `lds_dst` + lane*4.
+__device__ __forceinline__ void glds4(const void* gsrc, u32 lds_dst_any) {
+  asm volatile("" : "+v"(lds_dst_any));
+  const u32 lds_dst = (u32)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
+  u32 keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
@@ -1224,6 +1243,12 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int* cterm_h = wave_count + 16;
   int* tnb = cterm_h + n_pad;
   int* crow6h = tnb + n_pad / kTile;        // [wave][RT*32]: HEAD row terms 128*ra_head - 49024*D_head
+  // column sums (packed with the early-out) and tile bounds of image b, two buffers: the pair after the current one's is
+  // copied in by LDS-DMA while the current pair runs (no global load, hence no compiler vmcnt wait, at a pair boundary)
+  int* auxw = crow6h + kWaves * 64;         // [2][n_pad]
+  int* auxt = auxw + 2 * n_pad;             // [2][n_tiles_img]
+  int4* winfo = (int4*)(auxt + 2 * n_tiles_img);   // [kPairWindow] {p, a, b, n1 | n2 << 16}: pairs with work, in order
+  int* wmeta = (int*)(winfo + kPairWindow);        // [0] entries in the window
   constexpr int KH = head_steps_of(KS);
 #ifdef VC2_NO_EARLY
   constexpr bool kEarlyOut = false;
@@ -1266,11 +1291,49 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   const int lo = (int)(((long long)cid * n_pairs) / G);
   const int hi = (int)(((long long)(cid + 1) * n_pairs) / G);
 
-  PairInfo cur = next_pair_with_work(lo, hi, pairs, counts, n_max, prepared, img_stride);
-  if (tid == 0)
-    for (int q = lo; q < cur.p && q < hi; ++q) out_counts[q] = 0;   // empty images: nothing can match
+  // ---- the pairs of the range that have work, kPairWindow at a time ------------------------------------------------
+  // One wave reads 64 pairs and their counts at once, writes zero counts for those with an empty image and lists the
+  // others in LDS; the per-pair description is then an LDS read.  (Read pair by pair with scalar loads, two dependent
+  // round trips sat between every two pairs.)  fetch() is called by all waves at the same points, between pairs.
+  int w_i = 0, w_n = 0, w_base = lo;   // wave-uniform
+  auto fetch = [&]() -> PairInfo {
+    PairInfo r;
+    r.p = hi; r.a = 0; r.n1 = 0; r.n2 = 0; r.n_ct = 0; r.n_pass = 0; r.b_frags = prepared;
+    while (w_i == w_n) {
+      if (w_base >= hi) return r;
+      __syncthreads();   // nobody is still reading the list this round replaces
+      if (wave == kWaves - 1) {
+        const int q = w_base + lane;
+        int a = 0, b = 0, n1 = 0, n2 = 0;
+        if (q < hi) {
+          a = pairs[2 * q]; b = pairs[2 * q + 1];
+          n1 = min(max(counts[a], 0), n_max); n2 = min(max(counts[b], 0), n_max);
+        }
+        const bool work = q < hi && n1 > 0 && n2 > 0;
+        if (q < hi && !work) out_counts[q] = 0;   // an empty image: nothing can match
+        const unsigned long long mask = __ballot(work);
+        if (work) winfo[__popcll(mask & ((1ull << lane) - 1ull))] = make_int4(q, a, b, n1 | (n2 << 16));
+        if (lane == 0) wmeta[0] = __popcll(mask);
+      }
+      __syncthreads();
+      w_n = __builtin_amdgcn_readfirstlane(wmeta[0]);
+      w_i = 0;
+      w_base = min(w_base + kPairWindow, hi);
+    }
+    const int4 e = winfo[w_i++];
+    r.p = __builtin_amdgcn_readfirstlane(e.x);
+    r.a = __builtin_amdgcn_readfirstlane(e.y);
+    const int b = __builtin_amdgcn_readfirstlane(e.z);
+    const int nn = __builtin_amdgcn_readfirstlane(e.w);
+    r.n1 = nn & 0xffff; r.n2 = nn >> 16;
+    r.n_ct = ceil_div(r.n2, kTile);
+    r.n_pass = ceil_div(r.n1, kWaves * 2 * kTile);
+    r.b_frags = prepared + (size_t)b * img_stride;
+    return r;
+  };
+  PairInfo cur = fetch();
   if (cur.p >= hi) return;
-  PairInfo nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride);
+  PairInfo nxt = fetch();
 #ifdef VC_EXP_TRACE
   uint32_t* trace = out_matches + (size_t)lo * n_max * 2;
   const int trace_n = (int)(((size_t)(hi - lo) * n_max * 2) / 64);
@@ -1309,8 +1372,29 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int* pair_flag = wave_count + kWaves;   // "some tile of the current pair was relevant"
   // with the early-out the per-row word is the packed (head << 15 | tail) sum, else the plain row sum
   const int rs_off = kEarlyOut ? n_pad : 0;
-  int rb_pref = tid < cur.n_ct * kTile ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[rs_off + tid] : 0;
-  int tn_pref = (kEarlyOut && tid < cur.n_ct) ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[2 * n_pad + tid] : 0;
+  // Image b's column sums for pair X travel by LDS-DMA into aux buffer `par(X)`, issued by one LATE wave (which has no
+  // other copy in flight, so its vmcnt(0) waits for exactly these) when X becomes the next pair; they are read a whole
+  // pair later, after that wave's wait and the barrier that ends the pair in between.
+  constexpr int kAuxWave = kWaves / 2;
+  const u32 auxw_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(auxw));
+  const u32 auxt_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(auxt));
+  int aux_par = 0;   // buffer of the CURRENT pair
+  auto stage_aux = [&](const PairInfo& pi, int buf) {
+    if (wave == kAuxWave && pi.p < hi) {
+      int ln = lane;   // (laundered: lane-derived addresses are computed here, not carried across the tile loop)
+      asm volatile("" : "+v"(ln));
+      const uint8_t* sums = pi.b_frags + frag_bytes_img + (size_t)rs_off * 4;
+      const int pieces = ceil_div(pi.n_ct * kTile, 256);            // 1 KiB = 256 column words per piece
+      for (int i = 0; i < pieces; ++i)
+        glds16(sums + (size_t)i * 1024 + ln * 16, auxw_lds + (u32)(buf * n_pad * 4 + i * 1024));
+      if (kEarlyOut && ln < pi.n_ct)
+        glds4(pi.b_frags + frag_bytes_img + (size_t)2 * n_pad * 4 + ln * 4, auxt_lds + (u32)(buf * n_tiles_img * 4));
+    }
+  };
+  stage_aux(cur, 0);
+  stage_aux(nxt, 1);
+  if (wave == kAuxWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   // The two waves of a SIMD (w and w + 4) run half a tile apart, see pair_kernel.
 #ifdef VC2_NO_STAGGER
   constexpr bool late = false;
@@ -1336,7 +1420,6 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     const int n1 = cur.n1, n2 = cur.n2, n_ct = cur.n_ct, n_pass = cur.n_pass;
     const uint8_t* a_frags = prepared + (size_t)cur.a * img_stride;
     const int32_t* a_rowsum = (const int32_t*)(a_frags + frag_bytes_img);
-    const int32_t* b_rowsum = (const int32_t*)(cur.b_frags + frag_bytes_img);
 
     // ---- per-pair LDS state (the previous pair's finalisation ended with a barrier) ---------------------------
     // (columns 0..511 come from the register fetched during the previous pair: the load's latency was 2 k cycles
@@ -1353,9 +1436,9 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     // drains the LDS-DMA ring (the compiler cannot see the copies in flight).  A few more VALU instructions per pair.
     int tidp = tid;
     asm volatile("" : "+v"(tidp));
-    if (tidp < n_ct * kTile) init_column(tidp, rb_pref);
-    for (int j = tidp + kThreads; j < n_ct * kTile; j += kThreads) init_column(j, b_rowsum[rs_off + j]);
-    if (kEarlyOut && tidp < n_ct) tnb[tidp] = tn_pref;   // (n_ct <= 64 tiles; fetched during the previous pair)
+    const int* auxw_cur = auxw + aux_par * n_pad;
+    for (int j = tidp; j < n_ct * kTile; j += kThreads) init_column(j, auxw_cur[j]);
+    if (kEarlyOut && tidp < n_ct) tnb[tidp] = auxt[aux_par * n_tiles_img + tidp];
     for (int i = tidp; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
     if (tidp == 0) *pair_flag = 0;
     bool pair_hit = false;   // some tile of this wave held a relevant similarity
@@ -1407,19 +1490,20 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         for (int i = 0; i < BWindow<KS>::NB; ++i) asm volatile("" : "=v"(bf[i]));   // (no instruction: the old values die here)
         primed = false;
       };
-      auto mfma_tile = [&](int jt, const uint8_t* slot) -> int {
+      auto mfma_tile = [&](int jt, const uint8_t* slot, int cl, int hl) -> int {
         const bool have = primed;
         primed = primed_next;
         if (kEarlyOut && s_low >= 0 && (early_score >= 0 || --early_probe <= 0)) {   // (s_low = -1: nothing may be skipped)
-          const int thr = s_low - cterm_h[jt * kTile + c] - __mul24(tna, tnb[jt]);
-          const int r = mfma_phase2<KS, true>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, h, thr, produce);
+          const int thr = s_low - cterm_h[jt * kTile + cl] - __mul24(tna, tnb[jt]);
+          const int r = mfma_phase2<KS, true>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, hl, thr, produce);
           if (r != 0) early_score = min(early_score + 1, 8);
           else { early_score = max(early_score - 3, -8); early_probe = 32; }
           return r;
         }
-        return mfma_phase2<KS, false>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, h, 0, produce);
+        return mfma_phase2<KS, false>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, hl, 0, produce);
       };
       for (int jt = 0; jt < n_ct; ++jt) {
+        const int cl = c, hl = h;   // (laundering these per tile frees ~10 registers at ~1 % of throughput: not needed now)
         VC_TR(0, st_tp)
         // The barrier publishes this tile AND the next one of the ring (if it is in flight): the MFMA phase ends by
         // fetching the next tile's first fragments.
@@ -1447,21 +1531,21 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         VC_TR(1, st_tp)
         if (!late) {
           VC_TR(2, st_tp)
-          ct = cterm[jt * kTile + c];
-          cut = mfma_tile(jt, slot);
+          ct = cterm[jt * kTile + cl];
+          cut = mfma_tile(jt, slot, cl, hl);
           VC_ST(st_mfma)
           VC_TR(3, st_tp)
           VC_TR(5, cut)
         }
         const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
         const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, c, h, row_base, eth, cut, drop_window);
+        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, cl, hl, row_base, eth, cut, drop_window);
         VC_ST(st_epi)
         VC_TR(4, st_tp)
         if (late) {
           VC_TR(2, st_tp)
-          ct = cterm[jt * kTile + c];
-          cut = mfma_tile(jt, slot);
+          ct = cterm[jt * kTile + cl];
+          cut = mfma_tile(jt, slot, cl, hl);
           VC_ST(st_mfma)
           VC_TR(3, st_tp)
           VC_TR(5, cut)
@@ -1523,22 +1607,14 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       VC_ST(st_rowred)
     }  // passes
 
-    // column sums of the next pair's image b (consumed by its LDS initialisation)
     int tidf = tid;   // (as tidp: the finalisation's addresses are computed here, not carried through the tile loop)
     asm volatile("" : "+v"(tidf));
-#ifndef VC_EXP_NO_COLSUM
-    if (nxt.p < hi && tidf < nxt.n_ct * kTile) rb_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[rs_off + tidf];
-    if (kEarlyOut && nxt.p < hi && tidf < nxt.n_ct) tn_pref = ((const int32_t*)(nxt.b_frags + frag_bytes_img))[2 * n_pad + tidf];
-#endif
     if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
     __syncthreads();
     if (*pair_flag == 0) {
       // No tile of the pair held a similarity above the relevance threshold: every row's best stays below what the
       // angle test accepts, the match list is empty and nothing of the finalisation has to run.
-      if (tidf == 0) {
-        out_counts[p] = 0;
-        for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;
-      }
+      if (tidf == 0) out_counts[p] = 0;
     } else {
     // ---- angle + ratio tests, cross check, ordered compaction ---------------------------------------------------
     if (cross_check) {
@@ -1578,18 +1654,19 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       base += chunk_total;
       __syncthreads();
     }
-    if (tidf == 0) {
-      out_counts[p] = base;
-      for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;   // empty images between this pair and the next
+    if (tidf == 0) out_counts[p] = base;
     }
-    }
+    // the next pair's column sums (copied in during this pair) have landed before the barrier that lets it start
+    if (wave == kAuxWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the flag and the per-pair state are rewritten by the next pair's initialisation
 
     VC_ST(st_final)
     // ---- on to the next pair with work ---------------------------------------------------------------------------
     if (nxt.p >= hi) break;
     cur = nxt;
-    nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride);
+    nxt = fetch();
+    aux_par ^= 1;
+    stage_aux(nxt, aux_par ^ 1);   // (into the buffer of the pair that has just ended)
     if (p_on_next) {
       p_on_next = false;               // the producer's pair is the consumer's pair again
     }
