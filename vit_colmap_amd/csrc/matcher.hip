@@ -48,7 +48,13 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 __host__ __device__ inline int tiles_of(int n_max) { return ceil_div(ceil_div(n_max, kTile), 16) * 16; }
 __host__ __device__ inline int ksteps_of(int d) { return ceil_div(d, 32); }
 // K steps in the "head" of a descriptor for the exact early-out of pair2_kernel (== ks: no early-out for that length)
-__host__ __device__ constexpr int head_steps_of(int ks) { return ks == 12 ? 8 : (ks == 8 ? 4 : ks); }   // multiples of BWindow::NB
+#ifndef VC2_KH12
+#define VC2_KH12 4   // head k-steps of a 384-byte descriptor (a multiple of the window below)
+#endif
+#ifndef VC2_NB12
+#define VC2_NB12 4   // B window registers (fragments) at KS = 12
+#endif
+__host__ __device__ constexpr int head_steps_of(int ks) { return ks == 12 ? VC2_KH12 : (ks == 8 ? 4 : ks); }   // multiples of BWindow::NB
 // prepared image = fragments | row sums int32 [n_pad] | packed head / tail row sums int32 [n_pad] | per-tile tail norm bounds int32 [n_tiles]
 //   packed word   = (head << 15) | tail: sums of the row's bytes over the first head_steps_of(ks) * 32 dimensions and over the rest
 //   tail norm     = max over the tile's 32 rows of ceil(sqrt(sum of squared bytes over the remaining dimensions))
@@ -202,14 +208,18 @@ constexpr int kLdsBytes = 160 * 1024;
 constexpr int kRowScratchEntries = 16 * 33;
 constexpr int kRowScratchBytes = kRowScratchEntries * 8;
 constexpr int kMaxSlots = 8;  // PF <= 7 keeps "one tile in flight per wave" true for 8 waves
-constexpr int kPairWindow = 64;   // pair2_kernel: pairs-with-work described in LDS at a time (one wave builds the list)
+constexpr int kPairWindow = 32;   // pair2_kernel: pairs-with-work described in LDS at a time (half a wave builds the list)
 
 __host__ __device__ inline size_t lds_fixed_bytes(int n_pad) {
-  // (+ head column terms [n_pad], tail norm bounds of b's tiles [n_pad / 32], tail row terms [waves][64]: pair2_kernel's early-out)
-  // (+ pair2_kernel: two buffers of image b's column sums / tile bounds filled by LDS-DMA one pair ahead, the pair window)
-  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + kWaves * kRowScratchBytes + 64 +
-         (size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4 + kWaves * 64 * 4 + (size_t)n_pad * 4 /* ColState padding */ +
-         2 * ((size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4) + kPairWindow * 16 + 16;
+  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kWaves * 64 * 4 + kWaves * kRowScratchBytes + 64;
+}
+// pair2_kernel: column records of 16 bytes (best key, second, pad), column terms, m21 + row results, three row-term arrays per
+// wave (full, head, full - head), row-reduce scratch, head column terms + tile bounds of b, the copy of the NEXT pair's
+// column sums / tile bounds (LDS-DMA), the pair window
+__host__ __device__ inline size_t lds_fixed_bytes2(int n_pad) {
+  return (size_t)n_pad * (16 + 4 + 4 + 12) + 3 * (kWaves * 64 * 4) + kWaves * kRowScratchBytes + 64 +
+         (size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4 + ((size_t)n_pad * 4 + (size_t)(n_pad / kTile) * 4) +
+         kPairWindow * 16 + 16;
 }
 // number of ring slots for this problem size (0 = does not fit)
 inline int plan_slots(int ks, int n_pad) {
@@ -270,6 +280,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst_any) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
+}
+
+inline int plan_slots2(int ks, int n_pad) {
+  long ns = ((long)kLdsBytes - (long)lds_fixed_bytes2(n_pad)) / ((long)ks * kFragBytes);
+  if (ns > kMaxSlots) ns = kMaxSlots;
+  return ns >= 3 ? (int)ns : 0;
 }
 
 // One 256-byte LDS-DMA piece (64 lanes x 4 B; inactive lanes copy nothing): LDS destination = `lds_dst` + lane*4.
@@ -523,91 +539,93 @@ __device__ __forceinline__ void epilogue_phase(const v16i (&acc)[RT], u32 (&rbes
 // MFMA phase with C = row term: acc[rt][4q + i] starts at rterm[32 rt + 8 q + 4 h + i] (the row that register
 // holds in the 32x32 MFMA C layout), read from the wave's LDS slice straight into the accumulator registers,
 // so the result is sum (a-128)(b-128) + 128 ra - 49024 D and the column term is all that is left to add.
-// Exact early-out (descriptors of 129..384 bytes: head_steps_of(KS) < KS), EARLY = true.  The accumulators start from the
-// HEAD row term and the first KH k-steps give, per element, s_head - (head column term).  The rest of the dot product is
-// bounded by Cauchy-Schwarz on the unbiased bytes: sum over the tail of a b <= |a_tail| |b_tail| <= TNa TNb (per-tile maxima
-// of the rounded-up tail norms, computed by prepare_kernel).  If no lane holds  acc > s_low - cth - TNa TNb  the whole 32x32
-// tile stays at or below the relevance threshold whatever the tail holds, so its remaining KS - KH MFMAs per row tile and
-// its epilogue are skipped: nothing it could contribute would change the match list (see relevance_threshold()).
-// Otherwise the tile is computed again from the full row term with all KS steps (the plain path) — the caller then stays on
-// the plain path until a tile turns out irrelevant again, so data on which the test keeps failing pays for it once.
-// Returns 3 if the wave's two row tiles were cut short (accumulators meaningless: the epilogue skips them), else 0.
 // B operands come through a rolling window of NB fragment registers, D = NB - 1 k-steps ahead of the MFMAs that use them
 // (stamps: with one two-fragment group of look-ahead a wave alone on the pipe ran its 24 MFMAs in ~1300 cycles instead
-// of 768 — every group waited for an LDS read issued 128 pipe cycles earlier).  The window does not stop at the end of the
-// tile: the last D steps fetch fragments 0..D-1 of the NEXT tile of the ring (into bf[0..D-1], KS and the head being
-// multiples of NB), so the next phase starts with its first operands in registers.  That needs the next tile published
-// by the barrier in front of this one: the caller waits one tile further ahead and passes primed = false when the
-// tile was not in flight yet (tiny images, the very first tile) — then the window is filled here, latency exposed.
+// of 768 — every group waited for an LDS read issued 128 pipe cycles earlier).
+// Not kept (measured): letting the window run on into the NEXT tile of the ring (12 more registers live
+// across the epilogue: spills, and any spill reload near the tile loop makes the compiler wait for vmcnt, which drains the
+// LDS-DMA ring), and eight symmetric waves that issue the next tile's first reads in front of the barrier (12.3 M
+// pairs/s against 14.1 M with the staggered halves).
 template <int KS>
 struct BWindow {
-  static constexpr int NB = KS >= 4 ? 4 : KS;
+  static constexpr int NB = KS == 12 ? VC2_NB12 : (KS >= 4 ? 4 : KS);
   static constexpr int D = NB - 1;
-  static_assert(KS % NB == 0 && head_steps_of(KS) % NB == 0, "window positions must repeat from tile to tile");
+  static_assert(KS % NB == 0 && head_steps_of(KS) % NB == 0, "window positions must line up at the head boundary");
 };
 
-template <int KS, int N, typename Mid>
+// steps K0..K1-1 of a tile whose window is refilled up to fragment NF-1; `mid()` runs behind the MFMAs of step 0 (the
+// matrix pipe is busy for the next 64 cycles, which hides part of the issue cost of the LDS-DMA pieces placed there)
+template <int KS, int K0, int K1, int NF, typename Mid>
 __device__ __forceinline__ void mfma_steps(const v4i (&afrag)[2][KS], v16i (&acc)[2], v4i (&bf)[BWindow<KS>::NB],
-                                           const uint8_t* src, const uint8_t* nsrc, bool with_mid, Mid mid) {
+                                           const uint8_t* src, Mid mid) {
   constexpr int NB = BWindow<KS>::NB, D = BWindow<KS>::D;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
+  for (int k = K0; k < K1; ++k) {
     const int f = k + D;
-    if (NB > 1) bf[f % NB] = *(const v4i*)(f < N ? src + f * kFragBytes : nsrc + (f - N) * kFragBytes);
+    if (NB > 1 && f < NF) bf[f % NB] = *(const v4i*)(src + f * kFragBytes);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
       acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][k], bf[k % NB], acc[rt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (NB == 1) bf[0] = *(const v4i*)(k + 1 < N ? src + (k + 1) * kFragBytes : nsrc);
-    if (k == 0 && with_mid) mid();
+    if (NB == 1 && k + 1 < NF) bf[0] = *(const v4i*)(src + (k + 1) * kFragBytes);
+    if (k == 0) mid();
   }
 }
 
+// MFMA phase of one column tile.  EARLY (descriptors of 129..384 bytes): the accumulators start from the HEAD row term
+// and the first KH k-steps give, per element, s_head - (head column term).  The rest of the dot product is bounded by
+// Cauchy-Schwarz on the bytes themselves: sum over the tail of a b <= |a_tail| |b_tail| <= TNa TNb (per-tile maxima of
+// the rounded-up tail norms, from prepare_kernel), and the tail's share of the bias terms is known exactly — it is what
+// the head row / column terms leave out.  If no lane holds  acc > s_low - cth - TNa TNb  the whole 32x32 tile stays at
+// or below the relevance threshold whatever the tail holds: its remaining KS - KH MFMAs per row tile and its epilogue
+// are skipped (nothing it could contribute would change the match list, see relevance_threshold()).  Otherwise the
+// tile simply goes on: the tail MFMAs run on the same accumulators and the difference between the full and the head row
+// term (`rdelta`, one LDS word per register) is added afterwards — a failed test costs the test and 32 additions, no
+// MFMA is repeated.  Returns 3 if the wave's two row tiles were cut short (the epilogue skips them), else 0.
 template <int KS, bool EARLY, typename Mid>
-__device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], v4i (&bf)[BWindow<KS>::NB],
-                                           const uint8_t* slot, const uint8_t* next_slot, bool primed,
-                                           const int* rterm_wave, const int* rterm_head_wave, int lane, int h, int thr_early,
-                                           Mid mid) {
+__device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc)[2], const uint8_t* slot,
+                                           const int* rterm_wave, const int* rterm_head_wave, const int* rdelta_wave,
+                                           int lane, int h, int thr_early, Mid mid) {
   constexpr int RT = 2;
   constexpr int KH = head_steps_of(KS);
   constexpr int NB = BWindow<KS>::NB, D = BWindow<KS>::D;
   const uint8_t* src = slot + lane * 16;
-  const uint8_t* nsrc = next_slot + lane * 16;
 #ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(1);
 #endif
-  auto fill = [&]() {
+  v4i bf[NB];
 #pragma unroll
-    for (int i = 0; i < (NB > 1 ? D : 1); ++i) bf[i] = *(const v4i*)(src + i * kFragBytes);
-  };
-  auto init = [&](const int* rterm) {
+  for (int i = 0; i < (NB > 1 ? D : 1); ++i) bf[i] = *(const v4i*)(src + i * kFragBytes);
+  const int* rterm = EARLY ? rterm_head_wave : rterm_wave;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const v4i cr = *(const v4i*)(rterm + rt * kTile + 8 * q + 4 * h);
-        acc[rt][4 * q + 0] = cr[0]; acc[rt][4 * q + 1] = cr[1]; acc[rt][4 * q + 2] = cr[2]; acc[rt][4 * q + 3] = cr[3];
-      }
-  };
-  if (!primed) fill();   // wave-uniform
+    for (int q = 0; q < 4; ++q) {
+      const v4i cr = *(const v4i*)(rterm + rt * kTile + 8 * q + 4 * h);
+      acc[rt][4 * q + 0] = cr[0]; acc[rt][4 * q + 1] = cr[1]; acc[rt][4 * q + 2] = cr[2]; acc[rt][4 * q + 3] = cr[3];
+    }
   int cut = 0;
+  mfma_steps<KS, 0, KH, KS>(afrag, acc, bf, src, mid);
+  auto nothing = []() {};
   if (EARLY) {
-    init(rterm_head_wave);
-    mfma_steps<KS, KH>(afrag, acc, bf, src, nsrc, true, mid);   // (its last steps fetch the next tile: a cut is the common case)
     // one test for both row tiles of the wave (threshold from the larger of their two tail bounds)
     int m = max(acc[0][0], acc[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = max(m, max(acc[0][r], acc[1][r]));
-    if (__any(m > thr_early)) {   // may matter after all: the whole tile, plain
-      fill();
-      init(rterm_wave);
-      mfma_steps<KS, KS>(afrag, acc, bf, src, nsrc, false, mid);
+    if (__any(m > thr_early)) {   // may matter after all: the tail, then the part of the row term the head left out
+      mfma_steps<KS, KH, KS, KS>(afrag, acc, bf, src, nothing);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4i dr = *(const v4i*)(rdelta_wave + rt * kTile + 8 * q + 4 * h);
+          acc[rt][4 * q + 0] += dr[0]; acc[rt][4 * q + 1] += dr[1]; acc[rt][4 * q + 2] += dr[2]; acc[rt][4 * q + 3] += dr[3];
+        }
     } else {
       cut = 3;
     }
-  } else {
-    init(rterm_wave);
-    mfma_steps<KS, KS>(afrag, acc, bf, src, nsrc, true, mid);
+  } else if (KH < KS) {
+    mfma_steps<KS, KH, KS, KS>(afrag, acc, bf, src, nothing);
   }
 #ifndef VC2_NO_SETPRIO
   __builtin_amdgcn_s_setprio(0);
@@ -628,14 +646,9 @@ struct ColState {
 // The relevance test is cheap enough to run on every tile, so there is no separate "dense" regime here.
 // `ct` is read from LDS by the caller BEFORE the MFMA phase that precedes this call: read here it queued behind
 // the other waves' fragment reads (stamps: ~450 of an epilogue's 660 cycles).  Column merge as in epilogue_phase.
-// The update path wants ~30 temporaries: the B window (fetched ahead for the next tile, see mfma_phase2) is given up
-// there — `drop_window()` ends its registers' lifetime and tells the caller to refill — so that tiles without a relevant
-// entry keep the window and tiles with one do not spill (a spill reload in the tile loop makes the compiler wait for
-// vmcnt, which drains the LDS-DMA ring).
-template <typename Drop>
 __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbest)[2][16], u32 (&rsec)[2][16],
                                                 int ct, ColState* col,
-                                                int jt, int c, int h, u32 row_base, int s_low, int cut, Drop drop_window) {
+                                                int jt, int c, int h, u32 row_base, int s_low, int cut) {
   constexpr int RT = 2;
   const int thr = s_low == 0x7fffffff ? s_low : s_low - ct;   // acc > thr  <=>  acc + ct > s_low (|ct| < 2^27: no overflow)
   const u32 ctj = ((u32)ct << 6) + (63u - (u32)jt);           // key = (acc << 6) + ctj   (acc + ct >= 0)
@@ -649,7 +662,6 @@ __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbes
     for (int r = 1; r < 16; r += 2) m = max(m, r + 1 < 16 ? max(acc[rt][r], acc[rt][r + 1]) : acc[rt][r]);
     if (__any(m > thr)) {
       hit = true;
-      drop_window();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const u32 rk = ((u32)acc[rt][r] << 6) + ctj;
@@ -1232,7 +1244,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   const int n_pad = n_tiles_img * kTile;
   uint8_t* ring = smem;
   ColState* col = (ColState*)(smem + (size_t)ns * KS * kFragBytes);
-  int* cterm = (int*)(col + n_pad);
+  int* cterm = (int*)(col + n_pad);   // (kept out of the 16-byte column records: a stride-16 read is 4-way bank conflicted, -3 %)
   int* m21 = cterm + n_pad;
   int* rbest_s = m21 + n_pad;
   int* rsecond_s = rbest_s + n_pad;
@@ -1243,12 +1255,13 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int* cterm_h = wave_count + 16;
   int* tnb = cterm_h + n_pad;
   int* crow6h = tnb + n_pad / kTile;        // [wave][RT*32]: HEAD row terms 128*ra_head - 49024*D_head
-  // column sums (packed with the early-out) and tile bounds of image b, two buffers: the pair after the current one's is
-  // copied in by LDS-DMA while the current pair runs (no global load, hence no compiler vmcnt wait, at a pair boundary)
-  int* auxw = crow6h + kWaves * 64;         // [2][n_pad]
-  int* auxt = auxw + 2 * n_pad;             // [2][n_tiles_img]
-  int4* winfo = (int4*)(auxt + 2 * n_tiles_img);   // [kPairWindow] {p, a, b, n1 | n2 << 16}: pairs with work, in order
+  // column sums (packed with the early-out) and tile bounds of the NEXT pair's image b, copied in by LDS-DMA while the
+  // current pair runs (no global load, hence no compiler vmcnt wait, at a pair boundary)
+  int* auxw = crow6h + kWaves * 64;         // [n_pad]
+  int* auxt = auxw + n_pad;                 // [n_tiles_img]
+  int4* winfo = (int4*)(auxt + n_tiles_img);       // [kPairWindow] {p, a, b, n1 | n2 << 16}: pairs with work, in order
   int* wmeta = (int*)(winfo + kPairWindow);        // [0] entries in the window
+  int* crow6d = wmeta + 4;                         // [wave][RT*32]: full minus head row term (added when the early-out test fails)
   constexpr int KH = head_steps_of(KS);
 #ifdef VC2_NO_EARLY
   constexpr bool kEarlyOut = false;
@@ -1281,6 +1294,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   uint2* rscratch = (uint2*)(crow6 + kWaves * 64) + wave * kRowScratchEntries;  // this wave's slice
   int* crow6_wave = crow6 + wave * 64;
   int* crow6h_wave = crow6h + wave * 64;
+  int* crow6d_wave = crow6d + wave * 64;
   const size_t img_stride = image_bytes(n_tiles_img, KS);
   const size_t frag_bytes_img = (size_t)n_tiles_img * KS * kFragBytes;
   const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
@@ -1303,7 +1317,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       if (w_base >= hi) return r;
       __syncthreads();   // nobody is still reading the list this round replaces
       if (wave == kWaves - 1) {
-        const int q = w_base + lane;
+        const int q = lane < kPairWindow ? w_base + lane : hi;
         int a = 0, b = 0, n1 = 0, n2 = 0;
         if (q < hi) {
           a = pairs[2 * q]; b = pairs[2 * q + 1];
@@ -1372,27 +1386,26 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int* pair_flag = wave_count + kWaves;   // "some tile of the current pair was relevant"
   // with the early-out the per-row word is the packed (head << 15 | tail) sum, else the plain row sum
   const int rs_off = kEarlyOut ? n_pad : 0;
-  // Image b's column sums for pair X travel by LDS-DMA into aux buffer `par(X)`, issued by one LATE wave (which has no
-  // other copy in flight, so its vmcnt(0) waits for exactly these) when X becomes the next pair; they are read a whole
-  // pair later, after that wave's wait and the barrier that ends the pair in between.
+  // Image b's column sums for pair X travel by LDS-DMA into the aux buffer, issued by one LATE wave (which has no other
+  // copy in flight, so its vmcnt(0) waits for exactly these) behind the first barrier of the pair before X — every
+  // thread has read that pair's own sums by then — and are read a whole pair later, after that wave's wait and the
+  // barrier that ends the pair in between.
   constexpr int kAuxWave = kWaves / 2;
   const u32 auxw_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(auxw));
   const u32 auxt_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(auxt));
-  int aux_par = 0;   // buffer of the CURRENT pair
-  auto stage_aux = [&](const PairInfo& pi, int buf) {
+  auto stage_aux = [&](const PairInfo& pi) {
     if (wave == kAuxWave && pi.p < hi) {
       int ln = lane;   // (laundered: lane-derived addresses are computed here, not carried across the tile loop)
       asm volatile("" : "+v"(ln));
       const uint8_t* sums = pi.b_frags + frag_bytes_img + (size_t)rs_off * 4;
       const int pieces = ceil_div(pi.n_ct * kTile, 256);            // 1 KiB = 256 column words per piece
       for (int i = 0; i < pieces; ++i)
-        glds16(sums + (size_t)i * 1024 + ln * 16, auxw_lds + (u32)(buf * n_pad * 4 + i * 1024));
+        glds16(sums + (size_t)i * 1024 + ln * 16, auxw_lds + (u32)(i * 1024));
       if (kEarlyOut && ln < pi.n_ct)
-        glds4(pi.b_frags + frag_bytes_img + (size_t)2 * n_pad * 4 + ln * 4, auxt_lds + (u32)(buf * n_tiles_img * 4));
+        glds4(pi.b_frags + frag_bytes_img + (size_t)2 * n_pad * 4 + ln * 4, auxt_lds);
     }
   };
-  stage_aux(cur, 0);
-  stage_aux(nxt, 1);
+  stage_aux(cur);
   if (wave == kAuxWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // The two waves of a SIMD (w and w + 4) run half a tile apart, see pair_kernel.
@@ -1405,10 +1418,6 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int cur_a = -1, cur_tile0 = -1;
   int tna = 0;   // the larger tail norm bound of this wave's two row tiles (wave-uniform)
   int early_score = 0, early_probe = 0;   // gate of the early-out (wave-uniform, kept across pairs)
-  v4i bf[BWindow<KS>::NB];   // the B operand window, carried from tile to tile (mfma_phase2)
-#pragma unroll
-  for (int i = 0; i < BWindow<KS>::NB; ++i) bf[i] = v4i{0, 0, 0, 0};
-  bool primed = false;       // bf holds the first fragments of the tile about to be consumed (wave-uniform)
   v16i acc[RT];   // (the late half's first epilogue of a pass looks at stale accumulators behind an unreachable threshold)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -1426,8 +1435,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     // of every pair when it sat here)
     auto init_column = [&](int j, int word) {
       const int head = kEarlyOut ? (word >> 15) : 0, total = kEarlyOut ? head + (word & 0x7fff) : word;
-      cterm[j] = 128 * total + 32640 * d;
       if (kEarlyOut) cterm_h[j] = 128 * head + 32640 * d_head;
+      cterm[j] = 128 * total + 32640 * d;
       col[j].best = 0ull;
       col[j].second = 0u;
     };
@@ -1436,9 +1445,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     // drains the LDS-DMA ring (the compiler cannot see the copies in flight).  A few more VALU instructions per pair.
     int tidp = tid;
     asm volatile("" : "+v"(tidp));
-    const int* auxw_cur = auxw + aux_par * n_pad;
-    for (int j = tidp; j < n_ct * kTile; j += kThreads) init_column(j, auxw_cur[j]);
-    if (kEarlyOut && tidp < n_ct) tnb[tidp] = auxt[aux_par * n_tiles_img + tidp];
+    for (int j = tidp; j < n_ct * kTile; j += kThreads) init_column(j, auxw[j]);
+    if (kEarlyOut && tidp < n_ct) tnb[tidp] = auxt[tidp];
     for (int i = tidp; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
     if (tidp == 0) *pair_flag = 0;
     bool pair_hit = false;   // some tile of this wave held a relevant similarity
@@ -1459,7 +1467,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
           crow6_wave[lane] = 128 * total - 49024 * d;
           if (kEarlyOut) {
             crow6h_wave[lane] = 128 * head - 49024 * d_head;
-            tna = max(a_rowsum[2 * n_pad + tile0], a_rowsum[2 * n_pad + tile0 + 1]);
+            crow6d_wave[lane] = (128 * total - 49024 * d) - (128 * head - 49024 * d_head);
+            tna = __builtin_amdgcn_readfirstlane(max(a_rowsum[2 * n_pad + tile0], a_rowsum[2 * n_pad + tile0 + 1]));
           }
         }
         cur_a = cur.a;
@@ -1480,72 +1489,46 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       int ct = 0;   // column term of the tile whose epilogue comes next; always read ahead of an MFMA phase
       int cut = 0;  // row tiles of that tile the early-out cut short (wave-uniform)
       // thresholds of the early-out for column tile jt: acc_head > s_low - cth - TNa TNb  <=>  the tile may still matter
-      // When to try the early-out: a saturating score (+1 for a tile it cut short, -3 for a tile that had to be computed a
-      // second time in full) gates it, and while the score is negative one tile in 32 probes whether the data has changed.
-      // Non-matching data keeps it on; data on which the test fails half of the time or more pays ~1 % for the probes.
-      bool primed_next = false;
-      const uint8_t* next_slot = ring;
-      auto drop_window = [&]() {
-#pragma unroll
-        for (int i = 0; i < BWindow<KS>::NB; ++i) asm volatile("" : "=v"(bf[i]));   // (no instruction: the old values die here)
-        primed = false;
-      };
-      auto mfma_tile = [&](int jt, const uint8_t* slot, int cl, int hl) -> int {
-        const bool have = primed;
-        primed = primed_next;
+      // When to try it: a saturating score (+2 for a tile cut short, -1 for a failed test, which costs the test and the
+      // row-term fix-up but no MFMA) gates it, and while the score is negative one tile in 32 probes whether the data has
+      // changed.  It stays on while one test in three succeeds; data on which it never does pays < 1 % for the probes.
+      auto mfma_tile = [&](int jt, const uint8_t* slot) -> int {
         if (kEarlyOut && s_low >= 0 && (early_score >= 0 || --early_probe <= 0)) {   // (s_low = -1: nothing may be skipped)
-          const int thr = s_low - cterm_h[jt * kTile + cl] - __mul24(tna, tnb[jt]);
-          const int r = mfma_phase2<KS, true>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, hl, thr, produce);
-          if (r != 0) early_score = min(early_score + 1, 8);
-          else { early_score = max(early_score - 3, -8); early_probe = 32; }
+          const int thr = s_low - cterm_h[jt * kTile + c] - __mul24(tna, tnb[jt]);
+          const int r = mfma_phase2<KS, true>(afrag, acc, slot, crow6_wave, crow6h_wave, crow6d_wave, lane, h, thr, produce);
+          if (r != 0) early_score = min(early_score + 2, 8);
+          else { early_score = max(early_score - 1, -8); early_probe = 32; }
           return r;
         }
-        return mfma_phase2<KS, false>(afrag, acc, bf, slot, next_slot, have, crow6_wave, crow6h_wave, lane, hl, 0, produce);
+        return mfma_phase2<KS, false>(afrag, acc, slot, crow6_wave, crow6h_wave, crow6d_wave, lane, h, 0, produce);
       };
       for (int jt = 0; jt < n_ct; ++jt) {
-        const int cl = c, hl = h;   // (laundering these per tile frees ~10 registers at ~1 % of throughput: not needed now)
         VC_TR(0, st_tp)
-        // The barrier publishes this tile AND the next one of the ring (if it is in flight): the MFMA phase ends by
-        // fetching the next tile's first fragments.
-        const int lead = prod_seq - cons_seq;          // tiles staged and not yet consumed, this one included
-#ifdef VC2_XTILE
-        // (experiment: the window runs on into the next tile.  It needs 12 more live registers across the epilogue; the
-        // build spills, and a spill reload anywhere near this loop makes the compiler wait for vmcnt, which drains the
-        // LDS-DMA ring — 11.6 M pairs/s against 13.2 M.  Off until the registers are found.)
-        wait_tile<KS, kProd2>(wave, lead >= 2 ? lead - 2 : 0);
+        wait_tile<KS, kProd2>(wave, prod_seq - cons_seq - 1);
         wg_barrier();
-        primed_next = lead >= 2;
-#else
-        wait_tile<KS, kProd2>(wave, lead - 1);
-#ifdef VC_EXP_TRACE
-        VC_TR(6, stamp())
-#endif
-        wg_barrier();
-        primed_next = false;
-#endif
+        if (jt == 0 && pass == 0) stage_aux(nxt);   // (every thread is past this pair's initialisation)
         const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
         if (++cons_slot == ns) cons_slot = 0;
-        next_slot = ring + (size_t)cons_slot * KS * kFragBytes;
         ++cons_seq;
         VC_ST(st_wait)
         VC_TR(1, st_tp)
         if (!late) {
           VC_TR(2, st_tp)
-          ct = cterm[jt * kTile + cl];
-          cut = mfma_tile(jt, slot, cl, hl);
+          ct = cterm[jt * kTile + c];
+          cut = mfma_tile(jt, slot);
           VC_ST(st_mfma)
           VC_TR(3, st_tp)
           VC_TR(5, cut)
         }
         const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
         const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, cl, hl, row_base, eth, cut, drop_window);
+        pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, ejt, c, h, row_base, eth, cut);
         VC_ST(st_epi)
         VC_TR(4, st_tp)
         if (late) {
           VC_TR(2, st_tp)
-          ct = cterm[jt * kTile + cl];
-          cut = mfma_tile(jt, slot, cl, hl);
+          ct = cterm[jt * kTile + c];
+          cut = mfma_tile(jt, slot);
           VC_ST(st_mfma)
           VC_TR(3, st_tp)
           VC_TR(5, cut)
@@ -1554,7 +1537,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         ++trace_i;
 #endif
       }
-      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, n_ct - 1, c, h, row_base, s_low, cut, drop_window);
+      if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, n_ct - 1, c, h, row_base, s_low, cut);
       VC_ST(st_epi)
 
       // ---- row results of this pass (see pair_kernel) --------------------------------------------------------
@@ -1665,8 +1648,6 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     if (nxt.p >= hi) break;
     cur = nxt;
     nxt = fetch();
-    aux_par ^= 1;
-    stage_aux(nxt, aux_par ^ 1);   // (into the buffer of the pair that has just ended)
     if (p_on_next) {
       p_on_next = false;               // the producer's pair is the consumer's pair again
     }
@@ -2367,9 +2348,9 @@ int launch_pair2(const void* prepared, const int32_t* counts, int n_tiles, int d
                  uint32_t* out_matches, int32_t* out_counts, hipStream_t stream) {
   const int s_low = relevance_threshold(max_ratio, max_distance);
   const int n_pad = n_tiles * kTile;
-  const int ns = plan_slots(KS, n_pad);
+  const int ns = plan_slots2(KS, n_pad);
   if (ns < 3) return VC_ERR_UNSUPPORTED;
-  const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes(n_pad);
+  const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes2(n_pad);
   static vc::PerDeviceOnce configured;
   if (int st = configured.run([] {
         return hipFuncSetAttribute((const void*)pair2_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -2468,6 +2449,7 @@ int vc_match_pairs_u8(const void* prepared, const int32_t* counts, int n_images,
   if (n_max > VC_MAX_KEYPOINTS || d > VC_MAX_DESC_DIM) return VC_ERR_UNSUPPORTED;
   if (n_pairs == 0) return VC_OK;
 #if VC_WAVES == 8 && !defined(VC_OLD_PAIR_KERNEL)
+  int st2 = VC_ERR_UNSUPPORTED;
   switch (pick_ks(d)) {   // descriptors up to 384 bytes: the persistent kernel (two row tiles per wave)
 #ifdef VC_PAIR3_EXPERIMENT
 #define VC_LAUNCH_PERSISTENT launch_pair3
@@ -2476,15 +2458,18 @@ int vc_match_pairs_u8(const void* prepared, const int32_t* counts, int n_images,
 #endif
 #define VC_CASE2(K)                                                                                          \
   case K:                                                                                                    \
-    return VC_LAUNCH_PERSISTENT<K>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio,         \
-                                   max_distance, cross_check, n_max, out_matches, out_counts, (hipStream_t)stream);
+    st2 = VC_LAUNCH_PERSISTENT<K>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio,          \
+                                  max_distance, cross_check, n_max, out_matches, out_counts, (hipStream_t)stream); \
+    break;
     case 2:   // two MFMAs per row tile leave no room for the in-wave pipeline of pair3_kernel
-      return launch_pair2<2>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio, max_distance, cross_check, n_max,
-                             out_matches, out_counts, (hipStream_t)stream);
+      st2 = launch_pair2<2>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio, max_distance, cross_check, n_max,
+                            out_matches, out_counts, (hipStream_t)stream);
+      break;
     VC_CASE2(4) VC_CASE2(8) VC_CASE2(12)
 #undef VC_CASE2
     default: break;
   }
+  if (st2 != VC_ERR_UNSUPPORTED) return st2;   // (blocks too large for its LDS plan: the kernel with one workgroup per pair)
 #endif
   return dispatch_pair<true>(pick_ks(d), prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio,
                              max_distance, cross_check, n_max, out_matches, out_counts, nullptr,
