@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const v8bf*)(qp + 16 * ks + 8 * hh);
   }
+  // The Q loads have landed before the first LDS-DMA copy is issued.  Left pending, the compiler puts its waits for them at
+  // their first use — INSIDE the key-block loop, where they stay: s_waitcnt vmcnt(7) ... vmcnt(0) in front of the QK^T MFMAs
+  // of EVERY block, and since it cannot see the copies issued from inline asm, that vmcnt(0) also waited for the K / V copy
+  // issued a few instructions earlier for two blocks ahead (seen in the ISA with tools/isa_waits.sh; the trap of DESIGN.md
+  // §4.1).  Here the copy was an L2 hit that the second wave of the SIMD covered — 237 vs 239 us per layer — but the ring
+  // now really runs two blocks ahead.  (Not kept: K / V fragments through an explicit three-register window with
+  // sched_barriers, 241 us: the compiler's own [read, wait, 2 MFMAs] chain interleaves better with the other wave.)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched (gfx9 encoding)
 
   // K / V tiles (64 keys) go global -> LDS by LDS-DMA, two blocks ahead, into a ring of three
   // slots.  A block is 16 pieces of 1 KiB (8 keys x 128 B); wave w issues pieces 4w..4w+3.  The
