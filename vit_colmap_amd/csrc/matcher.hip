@@ -1233,6 +1233,10 @@ constexpr int kProd2 = kWaves;
 #else
 constexpr int kProd2 = kWaves / 2;   // LDS-DMA pieces are issued by the early half (waves 0..3)
 #endif
+#ifndef VC2_TILES_PER_BARRIER
+#define VC2_TILES_PER_BARRIER 2
+#endif
+constexpr int kTilesPerBarrier = VC2_TILES_PER_BARRIER;   // 1 or 2
 template <int KS>
 __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
@@ -1357,7 +1361,8 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   // It sweeps the current pair's image b once per row pass, then moves on to the NEXT pair (whose description is
   // already in registers), so the ring stays full across the pair boundary.  It never runs more than one pair
   // ahead: a next pair shorter than the ring leaves it idle until the consumer gets there.
-  const int pf = ns - 1;
+  const int tpb = ns >= 6 ? kTilesPerBarrier : 1;   // a short ring (large blocks) keeps its depth: one tile per barrier
+  const int pf = ns - tpb;
   const uint8_t* p_src = cur.b_frags;      // next tile to stage
   const uint8_t* p_base = cur.b_frags;
   int p_left = cur.n_ct, p_nct = cur.n_ct, p_sweeps = cur.n_pass;
@@ -1418,6 +1423,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   int cur_a = -1, cur_tile0 = -1;
   int tna = 0;   // the larger tail norm bound of this wave's two row tiles (wave-uniform)
   int early_score = 0, early_probe = 0;   // gate of the early-out (wave-uniform, kept across pairs)
+  bool pairs_dense = false;               // the previous pair held relevant similarities (workgroup-uniform)
   v16i acc[RT];   // (the late half's first epilogue of a pass looks at stale accumulators behind an unreachable threshold)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -1502,16 +1508,10 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         }
         return mfma_phase2<KS, false>(afrag, acc, slot, crow6_wave, crow6h_wave, crow6d_wave, lane, h, 0, produce);
       };
-      for (int jt = 0; jt < n_ct; ++jt) {
-        VC_TR(0, st_tp)
-        wait_tile<KS, kProd2>(wave, prod_seq - cons_seq - 1);
-        wg_barrier();
-        if (jt == 0 && pass == 0) stage_aux(nxt);   // (every thread is past this pair's initialisation)
-        const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
-        if (++cons_slot == ns) cons_slot = 0;
-        ++cons_seq;
-        VC_ST(st_wait)
-        VC_TR(1, st_tp)
+      // One barrier per TWO column tiles (with two thirds of the MFMAs gone a tile is ~2400 cycles of which ~590 went into
+      // the vmcnt wait, the barrier and the arrival skew).  The barrier publishes both tiles; the ring runs ns - 2 tiles
+      // ahead so that the copy issued during the second tile never lands in a slot a slower wave is still reading.
+      auto one_tile = [&](int jt, const uint8_t* slot) {
         if (!late) {
           VC_TR(2, st_tp)
           ct = cterm[jt * kTile + c];
@@ -1536,6 +1536,35 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
 #ifdef VC_EXP_TRACE
         ++trace_i;
 #endif
+      };
+      for (int jt = 0; jt < n_ct;) {
+        VC_TR(0, st_tp)
+        // (both tiles must be staged already: not so right after the producer idled — tiny images — or with a short ring)
+        // Pairs after one that held relevant similarities run one tile per barrier: with the update path in every
+        // epilogue the late half's deferred epilogue is the longer part and pairing the tiles loses 3 %.
+        const bool two = tpb == 2 && !pairs_dense && jt + 1 < n_ct && prod_seq - cons_seq >= 2;
+        // this wave's pieces of the tile(s) of this round have landed once only the younger tiles are pending
+        wait_tile<KS, kProd2>(wave, max(prod_seq - cons_seq - (two ? 2 : 1), 0));
+        wg_barrier();
+        if (jt == 0 && pass == 0) stage_aux(nxt);   // (every thread is past this pair's initialisation)
+        VC_ST(st_wait)
+        VC_TR(1, st_tp)
+        const int n_sub = two ? 2 : 1;
+        {
+          // (The second tile as a second trip through ONE copy of this body — a loop that is not unrolled — left out_counts
+          // unwritten for pairs with few rows and eight or more column tiles: the build is kept straight-line.)
+          const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
+          if (++cons_slot == ns) cons_slot = 0;
+          ++cons_seq;
+          one_tile(jt, slot);
+          if (two) {
+            const uint8_t* slot2 = ring + (size_t)cons_slot * KS * kFragBytes;
+            if (++cons_slot == ns) cons_slot = 0;
+            ++cons_seq;
+            one_tile(jt + 1, slot2);
+          }
+        }
+        jt += n_sub;
       }
       if (late) pair_hit |= epilogue_phase2(acc, rbest, rsec, ct, col, n_ct - 1, c, h, row_base, s_low, cut);
       VC_ST(st_epi)
@@ -1594,7 +1623,9 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     asm volatile("" : "+v"(tidf));
     if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
     __syncthreads();
-    if (*pair_flag == 0) {
+    const int pair_was_hit = __builtin_amdgcn_readfirstlane(*pair_flag);
+    pairs_dense = pair_was_hit != 0;   // (workgroup-uniform: every wave reads the same word behind the barrier)
+    if (pair_was_hit == 0) {
       // No tile of the pair held a similarity above the relevance threshold: every row's best stays below what the
       // angle test accepts, the match list is empty and nothing of the finalisation has to run.
       if (tidf == 0) out_counts[p] = 0;
