@@ -1035,25 +1035,30 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
   for (int i = tid; i < kGtBytes / 4; i += 512) ((uint32_t*)gt_l)[i] = ((const uint32_t*)gelu_tab)[i];
 
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0]);
-  // producer: waves 0-3 issue the W1 half of stage (chunk c1), waves 4-7 the W2 half (chunk c2), 6 pieces each
-  auto issue = [&](int c1, int c2, int slot) {
+  // producer: waves 0-3 issue the W1 half of a stage (chunk c1), waves 4-7 the W2 half (chunk c2), six pieces each.
+  // One piece: wave-uniform base in SGPRs + one per-lane offset
+  // shared by all pieces — with a 64-bit address per piece in VGPRs the compiler kept six pairs alive, spilled them,
+  // and every reload in the stage loop waited for vmcnt(0), i.e. for the copy just issued
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  auto issue_piece = [&](int c1, int c2, int slot, int i) {
     const int half = wave >> 2, q = wave & 3;
     const int c = half ? c2 : c1;
-    const uint8_t* src = Wm + (size_t)c * MStage + (size_t)half * XStage + (size_t)(q * 6) * 1024 + lane * 16;
-    const uint32_t dst = lds0 + (uint32_t)slot * MStage + (uint32_t)half * XStage + (uint32_t)(q * 6) * 1024u;
+    const uint8_t* sbase = Wm + (size_t)c * MStage + (size_t)half * XStage + (size_t)(q * 6 + i) * 1024;
+    const uint32_t dst = lds0 + (uint32_t)slot * MStage + (uint32_t)half * XStage + (uint32_t)(q * 6 + i) * 1024u;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(sbase), "s"(dst)
+        : "memory");
+  };
+  auto issue = [&](int c1, int c2, int slot) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %2\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(src + i * 1024), "s"(dst + (uint32_t)i * 1024u)
-          : "memory");
-    }
+    for (int i = 0; i < 6; ++i) issue_piece(c1, c2, slot, i);
   };
   typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1124,7 +1129,13 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       MS(0)
-      if (i <= n) issue_stage(i + 1, slot ^ 1);
+      // The six pieces of the next stage are issued BETWEEN this stage's MFMAs, one every four (round 2: issued in a
+      // block they held the wave for 300-650 cycles with its matrix pipe idle; in the fc2 waves, where the block sat
+      // behind the MFMAs, the copies' whole L2 latency was then waited for at the top of the next stage — ~750 cycles
+      // of every stage).  Stages without MFMAs issue them at once.
+      const bool do_issue = i <= n;
+      const int nc1 = chunk_of(min(max(i + 1, 0), n - 1)), nc2 = chunk_of(min(max(i - 1, 0), n - 1));
+      if (do_issue && !(i < n && i > 0)) issue_stage(i + 1, slot ^ 1);
       MS(1)
       if (i < n) {
         if (chunk == 0) {
@@ -1210,6 +1221,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
               hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
               if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
               gelu_slice(ks, (i - 1) & 1);
+              if ((ks & 3) == 1 && do_issue) issue_piece(nc1, nc2, slot ^ 1, ks >> 2);
               __builtin_amdgcn_sched_barrier(0);
             }
           } else {
@@ -1245,6 +1257,8 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       MS(0)
+      const bool do_issue = i <= n;
+      const int nc1 = chunk_of(min(max(i + 1, 0), n - 1)), nc2 = chunk_of(min(max(i - 1, 0), n - 1));
       if (i >= 2) {
         if (pchunk == 0) {
 #pragma unroll
@@ -1264,6 +1278,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           for (int q = 0; q < 24; ++q) {
             oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
             if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
+            if ((q & 3) == 1 && do_issue) issue_piece(nc1, nc2, slot ^ 1, q >> 2);   // (see the A waves)
           }
         }
 #ifdef VC_MLP_STAMP
@@ -1322,8 +1337,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
         if (++pchunk == n_chunks) pchunk = 0;
         MS(5)
       }
-      // the W2 half of the next stage is issued AFTER this wave's MFMAs: its partner issues the W1 half BEFORE its own
-      if (i <= n) issue_stage(i + 1, slot ^ 1);
+      if (do_issue && i < 2) issue_stage(i + 1, slot ^ 1);   // (no MFMAs to issue them between)
       MS(1)
       slot ^= 1;
     }
