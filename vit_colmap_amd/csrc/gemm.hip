@@ -273,6 +273,10 @@ __global__ void gelu_table_kernel(uint16_t* __restrict__ tab) {
   tab[i] = (uint16_t)f32_to_bf16_rne(y);
 }
 
+#ifndef VC_XS_ISSUE0
+#define VC_XS_ISSUE0 1        // MFMA behind which the first piece of stage i + 2 is issued ...
+#define VC_XS_ISSUE_STEP 4    // ... and the distance to the next (the last one stays ahead of the result stores at slice 19)
+#endif
 template <int EPI, bool LN, bool GT>
 __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X, const uint8_t* __restrict__ Wp,
                                                     const float* __restrict__ biasf, const __bf16* res,
@@ -298,25 +302,31 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds[0]);
   // ---- producer: wave w issues pieces 3w..3w+2 of every stage ------------------------------------
   int inb = s0 % n_nb, islot = 0, ileft = n;   // feature block / ring slot / stages left to issue
-  auto issue = [&]() {
-    const uint8_t* src = Wp + (size_t)inb * XStage + (size_t)(wave * 3) * 1024 + lane * 16;
-    const uint32_t dst = lds0 + (uint32_t)islot * XStage + (uint32_t)(wave * 3) * 1024u;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      uint32_t keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %2\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(src + i * 1024), "s"(dst + (uint32_t)i * 1024u)
-          : "memory");
+  // One piece: wave-uniform base in SGPRs + one per-lane offset (with per-piece 64-bit VGPR addresses the compiler keeps
+  // three pairs alive across the stage loop).  The last piece of a stage advances the stream.
+  const uint32_t lane_off16 = (uint32_t)lane * 16u;
+  auto issue_piece = [&](int i) {
+    const uint8_t* sbase = Wp + (size_t)inb * XStage + (size_t)(wave * 3 + i) * 1024;
+    const uint32_t dst = lds0 + (uint32_t)islot * XStage + (uint32_t)(wave * 3 + i) * 1024u;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off16), "s"(sbase), "s"(dst)
+        : "memory");
+    if (i == 2) {
+      // past the end the last stage is staged again into a slot nobody reads (keeps the vmcnt counts uniform)
+      if (ileft > 1) { --ileft; inb = inb + 1 == n_nb ? 0 : inb + 1; }
+      islot = islot + 1 == XNS ? 0 : islot + 1;
     }
-    // past the end the last stage is staged again into a slot nobody reads (keeps the vmcnt counts uniform)
-    if (ileft > 1) { --ileft; inb = inb + 1 == n_nb ? 0 : inb + 1; }
-    islot = islot + 1 == XNS ? 0 : islot + 1;
+  };
+  auto issue = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) issue_piece(i);
   };
 #pragma unroll
   for (int j = 0; j < XPF; ++j) issue();
@@ -587,15 +597,15 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
       for (int k = 0; k < 6; ++k) st_c[k] = 0;
     }
 #endif
-    // This wave's pieces of stage i (issued in iteration i-2) have landed once only operations issued after
-    // them are pending: per iteration a wave issues 3 pieces, then (residual epilogue) 2 loads, then the 2
-    // result stores of the pending block — 7 (+4) from iteration 3 on, fewer while the pipeline fills.
-    // Counting them keeps a wave from stalling on the write acknowledgement of its latest stores.
-    if (i >= 3) {
-      if (EPI == EPI_RESIDUAL) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    } else if (i == 2) {
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    // This wave's pieces of stage i (issued BETWEEN the MFMAs of iteration i-2) have landed once only operations issued
+    // after them are pending.  Per iteration a wave issues (residual epilogue) 2 loads, then inside the MFMA loop its 3
+    // pieces and the 2 result stores of the pending block: iteration i-1 alone accounts for 5 (+2) younger operations in
+    // every case — steady state, behind a row-tile switch (whose x loads drain everything older anyway) and while the
+    // pipeline fills from iteration 2 on; the stores of iteration i-2 that follow its last piece are not counted, so the
+    // wait is never too weak.  Counting keeps a wave from stalling on the write acknowledgement of its latest stores.
+    if (i >= 2) {
+      if (EPI == EPI_RESIDUAL) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     }
@@ -609,7 +619,8 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
 #else
     const bool reload = mt != mt_cur;
 #endif
-    issue();                                    // stage i + 2 into the slot read during iteration i - 1
+    // (stage i + 2 goes into the slot read during iteration i - 1: its three pieces are issued between this
+    // iteration's MFMAs — in a block behind the barrier they held every wave for 150-300 cycles with the matrix pipe idle)
     const int m_base = mt * XRows + wave * 32;
     if (reload) {
       // new row tile: the pending block cannot ride under this block's MFMAs (its x loads come first)
@@ -656,6 +667,8 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
           if (ks + XRD < XKS) wf[ks + XRD] = *(const v8bf*)(st + (ks + XRD) * 1024);
           slice(ks);
+          if (ks == VC_XS_ISSUE0 || ks == VC_XS_ISSUE0 + VC_XS_ISSUE_STEP || ks == VC_XS_ISSUE0 + 2 * VC_XS_ISSUE_STEP)
+            issue_piece((ks - VC_XS_ISSUE0) / VC_XS_ISSUE_STEP);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -663,6 +676,8 @@ __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X
         for (int ks = 0; ks < XKS; ++ks) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
           if (ks + XRD < XKS) wf[ks + XRD] = *(const v8bf*)(st + (ks + XRD) * 1024);
+          if (ks == VC_XS_ISSUE0 || ks == VC_XS_ISSUE0 + VC_XS_ISSUE_STEP || ks == VC_XS_ISSUE0 + 2 * VC_XS_ISSUE_STEP)
+            issue_piece((ks - VC_XS_ISSUE0) / VC_XS_ISSUE_STEP);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1012,6 +1027,10 @@ constexpr int M2OffG = M2OffTrB + 4 * XChunk;        // activation hand-off: [2 
 constexpr int M2Lds = M2OffG + 2 * 4 * 2048;         // 96 + 16 + 16 + 16 + 16 = 160 KiB
 static_assert(M2Lds <= 160 * 1024, "fused MLP: LDS budget");
 
+#ifndef VC_MLP_ISSUE0
+#define VC_MLP_ISSUE0 1       // first MFMA behind which a piece of the next stage is issued ...
+#define VC_MLP_ISSUE_STEP 3   // ... and the distance to the next one (sweep: 1+3k 228 us, 1+2k 229, 0+k 233, 1+4k 235)
+#endif
 __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, const uint8_t* __restrict__ Wm,
                                                       const float* __restrict__ b1f, const float* __restrict__ b2f,
                                                       int M, int n_chunks, int n_tiles, float eps,
@@ -1221,7 +1240,8 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
               hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
               if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
               gelu_slice(ks, (i - 1) & 1);
-              if ((ks & 3) == 1 && do_issue) issue_piece(nc1, nc2, slot ^ 1, ks >> 2);
+              if (ks >= VC_MLP_ISSUE0 && ks < VC_MLP_ISSUE0 + 6 * VC_MLP_ISSUE_STEP && (ks - VC_MLP_ISSUE0) % VC_MLP_ISSUE_STEP == 0 && do_issue)
+                issue_piece(nc1, nc2, slot ^ 1, (ks - VC_MLP_ISSUE0) / VC_MLP_ISSUE_STEP);
               __builtin_amdgcn_sched_barrier(0);
             }
           } else {
@@ -1278,7 +1298,8 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           for (int q = 0; q < 24; ++q) {
             oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
             if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
-            if ((q & 3) == 1 && do_issue) issue_piece(nc1, nc2, slot ^ 1, q >> 2);   // (see the A waves)
+            if (q >= VC_MLP_ISSUE0 && q < VC_MLP_ISSUE0 + 6 * VC_MLP_ISSUE_STEP && (q - VC_MLP_ISSUE0) % VC_MLP_ISSUE_STEP == 0 && do_issue)
+              issue_piece(nc1, nc2, slot ^ 1, (q - VC_MLP_ISSUE0) / VC_MLP_ISSUE_STEP);   // (see the A waves)
           }
         }
 #ifdef VC_MLP_STAMP
