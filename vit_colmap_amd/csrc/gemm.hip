@@ -275,7 +275,7 @@ __global__ void gelu_table_kernel(uint16_t* __restrict__ tab) {
 
 #ifndef VC_XS_ISSUE0
 #define VC_XS_ISSUE0 1        // MFMA behind which the first piece of stage i + 2 is issued ...
-#define VC_XS_ISSUE_STEP 4    // ... and the distance to the next (the last one stays ahead of the result stores at slice 19)
+#define VC_XS_ISSUE_STEP 8    // ... and the distance to the next (the last one stays ahead of the result stores at slice 19)
 #endif
 template <int EPI, bool LN, bool GT>
 __global__ __launch_bounds__(512, 1) void xs_kernel(const __bf16* __restrict__ X, const uint8_t* __restrict__ Wp,
