@@ -162,6 +162,31 @@ def test_persistent_ranges_more_pairs_than_cus(n_images, n_max, d, kind):
     assert_batch_equal(desc, counts, shuffled)
 
 
+@pytest.mark.parametrize("n_images,n_max,d", [(40, 512, 384), (36, 300, 256)])
+def test_sparse_pairs_with_planted_matches(n_images, n_max, d):
+    """Mostly non-matching descriptors (every tile cut short by the early-out, two column tiles per barrier) with
+    descriptors planted in some images: those pairs fail the head test on a few tiles (the restart-free continuation),
+    produce matches, and switch their workgroup between the one- and two-tile modes from pair to pair."""
+    rs = np.random.RandomState(7 * n_images + d)
+    desc, counts = image_set(300 + n_images, n_images, n_max, d, kind="vit")
+    counts = counts.copy()
+    counts[rs.permutation(n_images)[:6]] = rs.randint(1, n_max, 6)          # a few ragged images
+    donors = rs.permutation(n_images)[: n_images // 3]
+    for k in donors:                                                        # image k shares rows with image (k + 3) % n
+        j = (k + 3) % n_images
+        n = int(min(counts[k], counts[j]))
+        rows = rs.permutation(n)[: max(n // 8, 1)]
+        desc[j, rows] = desc[k, rs.permutation(n)[: len(rows)]]
+    desc = np.ascontiguousarray(desc)
+    pairs = mo.exhaustive_pairs(n_images)
+    # (negatives clipped by the reference's quantiser leave a row at ~0.5 similarity with ITSELF: angle 1.05, beyond the
+    # default max_distance of 0.7 — planted rows only match under a wider one)
+    gc = assert_batch_equal(desc, counts, pairs, max_distance=1.1)
+    assert gc.sum() > 100 and (gc == 0).sum() > len(pairs) // 2            # both kinds of pairs are present
+    perm = rs.permutation(len(pairs))
+    assert_batch_equal(desc, counts, np.ascontiguousarray(pairs[perm]), max_distance=1.1)   # no runs of image a
+
+
 @pytest.mark.parametrize("n_pairs", [1, 2, 7, 255, 256, 257, 263])
 def test_persistent_ranges_pair_counts_around_the_grid_size(n_pairs):
     n_images, n_max, d = 24, 64, 128
