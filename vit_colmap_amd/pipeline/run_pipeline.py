@@ -95,6 +95,13 @@ class Pipeline:
                 logger.warning("3D reconstruction skipped: pycolmap is not installed and incremental mapping is "
                                "outside the accelerated path")
             else:
+                with ColmapDatabase.open_database(str(db_path)) as db_check:
+                    n_verified = db_check.num_verified_image_pairs()
+                if n_verified == 0:
+                    # the mapper only reads two_view_geometries: on a database without verified pairs it returns no model
+                    # and says nothing
+                    logger.warning("no geometrically verified image pair in the database (two_view_geometries is empty): "
+                                   "incremental mapping will not find an initial pair")
                 sparse_dir = output_dir / "sparse"
                 sparse_dir.mkdir(parents=True, exist_ok=True)
                 reconstructions = pycolmap.incremental_mapping(
