@@ -209,10 +209,13 @@ def main():
     n_pairs_global = n_global * (n_global - 1) // 2
     out_m = torch.empty((my_pairs.shape[0], NUM_KEYPOINTS, 2), dtype=torch.int32, device=dev)
     out_c = torch.empty((my_pairs.shape[0],), dtype=torch.int32, device=dev)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     leg_ms = {"extract": 0.0, "gather": 0.0, "match": 0.0}
+    step_events = []                                         # four events per timed step, read after the timed region
 
     def step(timed):
+        # No host synchronisation inside a step: the K steps are enqueued back to back (the GPU never waits for Python to
+        # launch the next step's first kernels) and the timed region is closed by barrier() below.
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed:
             ev[0].record()
         res = ex.extract_device(frames)                      # preprocess + ViT + selection + descriptors
@@ -225,10 +228,7 @@ def main():
         match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
         if timed:
             ev[3].record()
-            torch.cuda.synchronize()
-            leg_ms["extract"] += ev[0].elapsed_time(ev[1])
-            leg_ms["gather"] += ev[1].elapsed_time(ev[2])
-            leg_ms["match"] += ev[2].elapsed_time(ev[3])
+            step_events.append(ev)
         return res
 
     def barrier():
@@ -251,6 +251,10 @@ def main():
         res = step(True)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    for ev in step_events:
+        leg_ms["extract"] += ev[0].elapsed_time(ev[1])
+        leg_ms["gather"] += ev[1].elapsed_time(ev[2])
+        leg_ms["match"] += ev[2].elapsed_time(ev[3])
 
     # ---- matcher leg at the BASELINE shape (configs[2]): 50 blocks of 512 x 384 per GPU, all pairs, this rank's share ----
     def matcher_loop(blocks_np):
