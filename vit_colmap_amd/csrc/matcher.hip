@@ -590,7 +590,7 @@ __device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc
   constexpr int KH = head_steps_of(KS);
   constexpr int NB = BWindow<KS>::NB, D = BWindow<KS>::D;
   const uint8_t* src = slot + lane * 16;
-#ifndef VC2_NO_SETPRIO
+#ifdef VC2_SETPRIO   // (raising the MFMA phase's priority paid on the round's earlier kernels; on the final one it costs the dense path 4 %)
   __builtin_amdgcn_s_setprio(1);
 #endif
   v4i bf[NB];
@@ -627,7 +627,7 @@ __device__ __forceinline__ int mfma_phase2(const v4i (&afrag)[2][KS], v16i (&acc
   } else if (KH < KS) {
     mfma_steps<KS, KH, KS, KS>(afrag, acc, bf, src, nothing);
   }
-#ifndef VC2_NO_SETPRIO
+#ifdef VC2_SETPRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
   return cut;
@@ -1413,12 +1413,11 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   stage_aux(cur);
   if (wave == kAuxWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // The two waves of a SIMD (w and w + 4) run half a tile apart, see pair_kernel.
-#ifdef VC2_NO_STAGGER
-  constexpr bool late = false;
-#else
-  const bool late = wave >= kWaves / 2;
-#endif
+  // The two waves of a SIMD (w and w + 4) run half a tile apart (see pair_kernel) on pairs that follow a pair with relevant
+  // similarities: there the epilogue is the long update path and the late half's runs under the early half's MFMAs (-6 %
+  // without).  On pairs without, the MFMA phase is 8 MFMAs and the epilogue a maximum and a ballot: all waves alike is
+  // 1.5-3 % faster.  `late` is set per pair (it must not change inside a pass: the late half's last epilogue is deferred).
+  const bool late_wave = wave >= kWaves / 2;
   v4i afrag[RT][KS];
   int cur_a = -1, cur_tile0 = -1;
   int tna = 0;   // the larger tail norm bound of this wave's two row tiles (wave-uniform)
@@ -1456,6 +1455,13 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     for (int i = tidp; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
     if (tidp == 0) *pair_flag = 0;
     bool pair_hit = false;   // some tile of this wave held a relevant similarity
+#if defined(VC2_NO_STAGGER)
+    const bool late = false;
+#elif defined(VC2_ALWAYS_STAGGER)
+    const bool late = late_wave;
+#else
+    const bool late = late_wave && pairs_dense;
+#endif
 
     for (int pass = 0; pass < n_pass; ++pass) {
       const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
