@@ -1422,586 +1422,6 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   const bool late = wave >= kWaves / 2;
 #endif
   v4i afrag[RT][KS];
-  {
-    const int tile0 = wave * RT;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
-        afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
-  }
-  int rowsum0 = 0;
-  if (lane < RT * kTile) rowsum0 = a_rowsum[wave * RT * kTile + lane];
-
-  constexpr int kRowsPerPass = kWaves * RT * kTile;
-  const int n_ct = ceil_div(n2, kTile);  // column tiles of b that hold valid rows
-  const int n_pass = ceil_div(n1, kRowsPerPass);
-  const int total = n_pass * n_ct;       // tiles consumed, in order (pass, jt)
-#ifdef VC_INWAVE_LOOP
-  // RT = 2 consumes two tiles per barrier, so a refill may only target the two slots of the previous iteration
-  const int pf = RT == 2 ? ns - 2 : ns - 1;
-#else
-  const int pf = ns - 1;
-#endif
-
-  if (total == 0) {  // an empty image: nothing can match (uniform exit)
-    if (FUSED) { if (tid == 0) out_counts[p] = 0; }
-    else for (int i = tid; i < n1; i += kThreads) { o_idx[i] = -1; o_best[i] = 0; o_second[i] = 0; }
-    return;
-  }
-
-  // ---- per-pair LDS state ----------------------------------------------------------------
-  for (int j = tid; j < n_ct * kTile; j += kThreads) {
-    cterm[j] = 128 * b_rowsum[j] + 32640 * d;
-    colbest[j] = 0ull;
-    colsecond[j] = 0u;
-  }
-  if (FUSED)  // defaults for rows whose reduction round is skipped (ordered by the tile barriers)
-    for (int i = tid; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
-  const int rbias = -49024 * d;
-  int* crow6_wave = crow6 + wave * 64;
-  const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
-
-  // producer / consumer cursors over the tile sequence
-  int prod_seq = 0, prod_jt = 0, prod_slot = 0;
-  for (; prod_seq < pf && prod_seq < total; ++prod_seq) {
-    stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
-    if (++prod_jt == n_ct) prod_jt = 0;
-    if (++prod_slot == ns) prod_slot = 0;
-  }
-  int cons_seq = 0, cons_slot = 0;
-  // The two waves of a SIMD (w and w+4) run half a tile apart: while waves 0-3 issue the MFMAs of
-  // tile t, waves 4-7 run the VALU epilogue of tile t-1, and vice versa, so the matrix pipe and the
-  // vector pipe of a SIMD work at the same time instead of being fought over in lockstep.
-#ifndef VC_NO_STAGGER
-  // (with four-wave workgroups the SIMD partner is a wave of the other workgroup on the CU: no stagger)
-  const bool late = kWaves == 8 && wave >= kWaves / 2;
-#else
-  constexpr bool late = false;
-#endif
-
-  for (int pass = 0; pass < n_pass; ++pass) {
-    const int tile0 = (pass * kWaves + wave) * RT;  // first 32-row tile of a owned by this wave
-    // A fragments stay in registers for the whole pass (every tile index exists: tiles_of());
-    // pass 0's were requested at kernel entry.
-    u32 rbest[RT][16], rsec[RT][16];
-    int rowsum = rowsum0;
-    if (pass > 0) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-          afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
-      if (lane < RT * kTile) rowsum = a_rowsum[tile0 * kTile + lane];
-    }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
-    // row term of this lane's row (lane <-> row tile0*32 + lane of the wave's RT*32 rows)
-    if (lane < RT * kTile) crow6_wave[lane] = 128 * rowsum + rbias;
-    const u32 row_base = (u32)(tile0 * kTile);
-    bool dense[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) dense[rt] = false;
-    v16i acc[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][r] = 0;
-
-    // one iteration = one column tile: wait for it, barrier, then the two phases in the order of
-    // this wave's half
-#define VC_TILE_HEAD()                                                                              \
-    wait_tile<KS>(wave, prod_seq - cons_seq - 1);                                                   \
-    wg_barrier();                                                                                   \
-    const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;                               \
-    if (++cons_slot == ns) cons_slot = 0;                                                           \
-    ++cons_seq;
-    // refill of the slot freed by the previous iteration; legal anywhere after the barrier
-    auto produce = [&]() {
-      if (prod_seq < total) {
-        stage_tile<KS>(b_frags + (size_t)prod_jt * KS * kFragBytes,
-                       ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
-        ++prod_seq;
-        if (++prod_jt == n_ct) prod_jt = 0;
-        if (++prod_slot == ns) prod_slot = 0;
-      }
-    };
-
-#ifdef VC_INWAVE_LOOP
-    if constexpr (RT == 2) {
-      // ---- in-wave pipelined loop: see the comment above RelevancePass ----------------------------------
-      int ct_prev = 0;
-#ifdef VC_EXP_STAMP
-      unsigned long long sw = 0, sm = 0, se = 0;
-      const unsigned long long t_begin = stamp();
-      unsigned long long tp = t_begin;
-#define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - tp; tp = t_; }
-#else
-#define VC_ST(acc_)
-#endif
-      // one column tile: both halves, and the refill of one ring slot
-      auto process_tile = [&](int jt, const uint8_t* slot) {
-        const int ct = cterm[jt * kTile + c];
-        const uint8_t* src = slot + lane * 16;
-        RelevancePass p1;
-        v4i bf_io[kRd];
-#pragma unroll
-        for (int i = 0; i < (KS < kRd ? KS : kRd); ++i) bf_io[i] = *(const v4i*)(src + i * kFragBytes);
-        __builtin_amdgcn_sched_barrier(0);
-        // first half: row tile 0 of column tile jt  ||  relevance pass of row tile 1 of column tile jt-1
-        // (jt = 0: the accumulators are the zeros written above; an unreachable threshold neutralises it)
-        mfma_half<KS, true>(afrag[0], acc[0], src, bf_io, [&](int i) {
-          if (i == (KS > 1 ? 1 : 0)) produce();
-          relevance_steps<KS>(i, acc[1], crow6_wave + kTile, h, ct_prev, p1);
-        });
-        VC_ST(sm)
-        if (dense[1] || __any(p1.m > (jt > 0 ? s_low : 0x7fffffff)))
-          dense[1] = update_tile<FUSED>(acc[1], rbest[1], rsec[1], crow6_wave + kTile, ct_prev, jt - 1, 1, c, h,
-                                        row_base, s_low, colbest, colsecond);
-        VC_ST(se)
-        // second half: row tile 1 of column tile jt  ||  relevance pass of row tile 0 of column tile jt
-        mfma_half<KS, false>(afrag[1], acc[1], src, bf_io, [&](int i) { relevance_steps<KS>(i, acc[0], crow6_wave, h, ct, p1); });
-        VC_ST(sm)
-        if (dense[0] || __any(p1.m > s_low))
-          dense[0] = update_tile<FUSED>(acc[0], rbest[0], rsec[0], crow6_wave, ct, jt, 0, c, h, row_base, s_low,
-                                        colbest, colsecond);
-        VC_ST(se)
-        ct_prev = ct;
-      };
-      // Two column tiles per workgroup barrier: the waves of a SIMD drift apart by hundreds of cycles per
-      // tile (the younger one loses issue arbitration), and every barrier turns that drift into idle time.
-      for (int jt = 0; jt < n_ct; jt += 2) {
-        const bool two = jt + 1 < n_ct;
-        // the later of the tiles consumed in this iteration must have landed
-        wait_tile<KS>(wave, prod_seq - cons_seq - (two ? 2 : 1));
-        wg_barrier();
-        const uint8_t* slot0 = ring + (size_t)cons_slot * KS * kFragBytes;
-        if (++cons_slot == ns) cons_slot = 0;
-        const uint8_t* slot1 = ring + (size_t)cons_slot * KS * kFragBytes;
-        if (two && ++cons_slot == ns) cons_slot = 0;
-        cons_seq += two ? 2 : 1;
-        VC_ST(sw)
-        process_tile(jt, slot0);
-        if (two) process_tile(jt + 1, slot1);
-      }
-#ifdef VC_EXP_STAMP
-      if (FUSED && lane == 0 && pass == 0) {
-        uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
-        dbg[0] = (uint32_t)sw; dbg[1] = (uint32_t)sm; dbg[2] = (uint32_t)se;
-        dbg[3] = (uint32_t)(tp - t_begin); dbg[4] = (uint32_t)(t_begin - t_kernel_start);
-      }
-#endif
-#undef VC_ST
-      {  // row tile 1 of the last column tile has no MFMAs to ride under
-        RelevancePass p1;
-#pragma unroll
-        for (int i = 0; i < KS; ++i) relevance_steps<KS>(i, acc[1], crow6_wave + kTile, h, ct_prev, p1);
-        if (dense[1] || __any(p1.m > s_low))
-          dense[1] = update_tile<FUSED>(acc[1], rbest[1], rsec[1], crow6_wave + kTile, ct_prev, n_ct - 1, 1, c, h,
-                                        row_base, s_low, colbest, colsecond);
-      }
-    } else
-#endif
-    {
-    // Staggered halves (late = waves 4-7): one loop, the epilogue shared, only the MFMA phase
-    // placed before or after it.  The late half runs the epilogue of tile jt-1; for jt = 0 that
-    // call is neutralised by an unreachable threshold (its accumulators are not defined yet).
-#ifdef VC_EXP_STAMP
-    unsigned long long sw = 0, sm = 0, se = 0, sm2 = 0;
-    const unsigned long long t_begin = stamp();
-    unsigned long long tp = t_begin;
-#endif
-    for (int jt = 0; jt < n_ct; ++jt) {
-      VC_TILE_HEAD()
-#ifdef VC_EXP_STAMP
-      unsigned long long ta = stamp(); sw += ta - tp;
-#endif
-      if (!late) mfma_phase<KS, RT>(afrag, acc, slot, lane, produce);
-#ifdef VC_EXP_STAMP
-      unsigned long long tb = stamp(); sm += tb - ta;
-#endif
-      const int ejt = late ? (jt > 0 ? jt - 1 : 0) : jt;
-      const int eth = (late && jt == 0) ? 0x7fffffff : s_low;
-      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, ejt, c, h, row_base, eth, dense);
-#ifdef VC_EXP_STAMP
-      unsigned long long tc = stamp(); se += tc - tb;
-#endif
-      if (late) mfma_phase<KS, RT>(afrag, acc, slot, lane, produce);
-#ifdef VC_EXP_STAMP
-      tp = stamp(); sm2 += tp - tc;
-#endif
-    }
-#ifdef VC_EXP_STAMP
-    if (FUSED && lane == 0 && pass == 0) {
-      uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
-      dbg[0] = (uint32_t)sw; dbg[1] = (uint32_t)(sm + sm2); dbg[2] = (uint32_t)se;
-      dbg[3] = (uint32_t)(tp - t_begin); dbg[4] = (uint32_t)(t_begin - t_kernel_start);
-    }
-#endif
-    if (late)
-      epilogue_phase<RT, FUSED>(acc, rbest, rsec, crow6_wave, cterm, colbest, colsecond, n_ct - 1, c, h, row_base, s_low, dense);
-    }
-#undef VC_TILE_HEAD
-
-    // ---- row results of this pass ------------------------------------------------------
-    // Each row's candidates sit in 32 lanes (one per column residue c).  Transpose through a
-    // wave-private LDS slice, 16 rows per round: lane (c, h) writes its {best, second} keys of
-    // 8 registers, then lane L re-reads row L>>2, columns 8*(L&3) .. +7 in ascending order
-    // (strict '>' keeps the lowest column on ties) and the four partial results of a row are
-    // folded with two quad-permute steps.  No workgroup barrier: the slice belongs to the wave
-    // and its LDS operations execute in order.
-#ifdef VC_EXP_NO_ROWREDUCE
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(rbest[rt][r]), "v"(rsec[rt][r]));
-    if (false)
-#endif
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        // a round whose 16 rows never saw a relevant similarity keeps the (0, 0, -1) defaults
-        u32 seen = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) seen |= rbest[rt][8 * half + j];
-        if (FUSED && !__any(seen != 0)) continue;  // (the one-way API reports every row)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = 8 * half + j;
-          rscratch[(j + 8 * h) * 33 + c] = make_uint2(rbest[rt][r], rsec[rt][r]);
-        }
-        const int rl = lane >> 2, qd = lane & 3;       // row of the round, column quarter
-        u32 rb = 0, rs = 0, rc = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint2 en = rscratch[rl * 33 + qd * 8 + e];
-          const bool gt = en.x > rb;
-          rs = gt ? umax(rb, en.y) : umax(rs, en.x);
-          rc = gt ? (u32)(qd * 8 + e) : rc;
-          rb = umax(rb, en.x);
-        }
-        // fold quarters: the lower quarter absorbs the higher one (strict '>': lower column wins)
-#pragma unroll
-        for (int step = 0; step < 2; ++step) {
-          u32 pb, ps, pc;
-          if (step == 0) { pb = dpp_mov<0xB1>(rb); ps = dpp_mov<0xB1>(rs); pc = dpp_mov<0xB1>(rc); }   // quad_perm [1,0,3,2]
-          else           { pb = dpp_mov<0x4E>(rb); ps = dpp_mov<0x4E>(rs); pc = dpp_mov<0x4E>(rc); }   // quad_perm [2,3,0,1]
-          const bool gt = pb > rb;
-          rs = gt ? umax(rb, ps) : umax(rs, pb);
-          rc = gt ? pc : rc;
-          rb = umax(rb, pb);
-        }
-        // row of this lane's result inside the wave's RT*32 rows (see the MFMA C layout)
-        const int jj = rl & 7, hh = rl >> 3;
-        const int lrow = (jj & 3) + 16 * half + 8 * (jj >> 2) + 4 * hh;
-        if (qd == 0) {
-          const int row = (tile0 + rt) * kTile + lrow;
-          if (row < n1) {
-            const int sb = (int)(rb >> 6);
-            const int idx = sb > 0 ? (63 - (int)(rb & 63)) * kTile + (int)rc : -1;
-            const int s2v = sb > 0 ? (int)(rs >> 6) : 0;
-            if (FUSED) { rbest_s[row] = sb; rsecond_s[row] = s2v; ridx_s[row] = idx; }
-            else { o_idx[row] = idx; o_best[row] = sb; o_second[row] = s2v; }
-          }
-        }
-      }
-    }
-  }  // passes
-
-  if (!FUSED) return;
-#ifdef VC_EXP_NO_FINALIZE
-  if (tid == 0) out_counts[p] = 0;
-  return;
-#endif
-  __syncthreads();
-
-  // ---- angle + ratio tests, cross check, ordered compaction -----------------------------
-  if (cross_check) {
-    for (int j = tid; j < n2; j += kThreads) {
-      const unsigned long long kb = colbest[j];
-      const int sb = (int)(kb >> 32);
-      const int row = (int)(0xFFFFFFFFu - (u32)kb);
-      m21[j] = accept_dev(sb, (int)colsecond[j], max_ratio, max_distance) ? row : -1;
-    }
-  }
-  __syncthreads();
-  uint32_t* out = out_matches + (size_t)p * n_max * 2;
-  int base = 0;
-  for (int i0 = 0; i0 < n1; i0 += kThreads) {
-    const int i = i0 + tid;
-    bool ok = false;
-    int j = -1;
-    if (i < n1) {
-      j = ridx_s[i];
-      ok = accept_dev(rbest_s[i], rsecond_s[i], max_ratio, max_distance);
-      if (ok && cross_check) ok = (m21[j] == i);
-    }
-    const unsigned long long mask = __ballot(ok);
-    if (lane == 0) wave_count[wave] = __popcll(mask);
-    __syncthreads();
-    int before = base;
-    for (int w = 0; w < wave; ++w) before += wave_count[w];
-    int chunk_total = 0;
-    for (int w = 0; w < kWaves; ++w) chunk_total += wave_count[w];
-    if (ok) {
-      const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
-      out[2 * pos] = (uint32_t)i;
-      out[2 * pos + 1] = (uint32_t)j;
-    }
-    base += chunk_total;
-    __syncthreads();
-  }
-  if (tid == 0) out_counts[p] = base;
-#ifdef VC_EXP_STAMP
-  if (lane == 0) {
-    const unsigned long long t_end = stamp();
-    uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
-    dbg[5] = (uint32_t)(t_end - t_kernel_start);
-  }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------
-// The persistent pair kernel (KS <= 12, two row tiles per wave): what vc_match_pairs_u8 launches.
-// ---------------------------------------------------------------------------------------
-// Same arithmetic, tile loop and LDS layout as pair_kernel<KS, 2, true>; what differs is everything AROUND
-// the tile loop, which is where a workgroup of pair_kernel spent a third of its time with the matrix pipe idle
-// (measured: a launch with epilogue, staging and finalisation compiled out still ran at 55 % of the int8 peak):
-//   * one workgroup per CU walks a CONTIGUOUS range of the pair list.  The exhaustive list is ordered by
-//     image a, so consecutive pairs share it: the A fragments (96 VGPRs per wave, 192 KiB per workgroup) are
-//     re-fetched only when a (or the row pass) changes, not once per pair;
-//   * the B ring never drains: the producer cursor runs over the flattened (pair, pass, column tile) sequence,
-//     so the first tiles of the next pair are already in LDS while the current one is finalised;
-//   * the next pair's column sums are fetched into registers before the current pair's tile loop;
-//   * the angle / ratio tests read theta from a table (accept_tab) — no double-precision acos, so the
-//     finalisation is short and its registers do not collide with the fragments that stay live across it;
-//   * the accumulators start from the row term (read from LDS as the MFMA's C operand) instead of zero: the
-//     relevance test of a 32x32 tile is then a maximum over the lane's 16 accumulators against a per-lane
-//     threshold (9 VALU instead of 24), and an update key is one shift-add.
-// Block -> range mapping: blocks b and b + 8 share an XCD (round robin), so ranges are dealt such that each
-// XCD owns a contiguous eighth of the pair list (neighbouring pairs share image a in that XCD's L2).
-struct PairInfo {     // wave-uniform description of one pair with work (n_ct * n_pass > 0)
-  int p;              // index in the pair list (>= hi: none)
-  int a, n1, n2, n_ct, n_pass;
-  const uint8_t* b_frags;
-};
-
-// first pair at or after `p` that has tiles to process (scalar loads; runs once per pair, outside the tile loop)
-__device__ __forceinline__ PairInfo next_pair_with_work(int p, int hi, const int32_t* __restrict__ pairs,
-                                                        const int32_t* __restrict__ counts, int n_max,
-                                                        const uint8_t* __restrict__ prepared, size_t img_stride,
-                                                        int rows_per_pass = kWaves * 2 * kTile) {
-  PairInfo r;
-  r.a = 0; r.n1 = 0; r.n2 = 0; r.n_ct = 0; r.n_pass = 0; r.b_frags = prepared;
-  for (; p < hi; ++p) {
-    const int a = pairs[2 * p], b = pairs[2 * p + 1];
-    const int n1 = min(max(counts[a], 0), n_max), n2 = min(max(counts[b], 0), n_max);
-    if (n1 > 0 && n2 > 0) {
-      r.a = a; r.n1 = n1; r.n2 = n2;
-      r.n_ct = ceil_div(n2, kTile);
-      r.n_pass = ceil_div(n1, rows_per_pass);
-      r.b_frags = prepared + (size_t)b * img_stride;
-      break;
-    }
-  }
-  r.p = p;
-  return r;
-}
-
-#ifdef VC2_ALL_PRODUCE
-constexpr int kProd2 = kWaves;
-#else
-constexpr int kProd2 = kWaves / 2;   // LDS-DMA pieces are issued by the early half (waves 0..3)
-#endif
-#ifndef VC2_TILES_PER_BARRIER
-#define VC2_TILES_PER_BARRIER 2
-#endif
-constexpr int kTilesPerBarrier = VC2_TILES_PER_BARRIER;   // 1 or 2
-template <int KS>
-__global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
-    const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
-    const int32_t* __restrict__ pairs, int n_pairs, float max_ratio, float max_distance, int cross_check,
-    int n_max, int ns, int s_low, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts) {
-  static_assert(kWaves == 8, "the persistent kernel is written for eight-wave workgroups");
-  constexpr int RT = 2;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int n_pad = n_tiles_img * kTile;
-  uint8_t* ring = smem;
-  ColState* col = (ColState*)(smem + (size_t)ns * KS * kFragBytes);
-  int* cterm = (int*)(col + n_pad);   // (kept out of the 16-byte column records: a stride-16 read is 4-way bank conflicted, -3 %)
-  int* m21 = cterm + n_pad;
-  int* rbest_s = m21 + n_pad;
-  int* rsecond_s = rbest_s + n_pad;
-  int* ridx_s = rsecond_s + n_pad;
-  int* crow6 = ridx_s + n_pad;              // [wave][RT*32]: row terms 128*ra - 49024*D (the HEAD part with the early-out)
-  int* wave_count = crow6 + kWaves * 64 + kWaves * kRowScratchBytes / 4;
-  // early-out state (head_steps_of(KS) < KS): head column terms, tail norm bounds of b's tiles, tail row terms per wave
-  int* cterm_h = wave_count + 16;
-  int* tnb = cterm_h + n_pad;
-  int* crow6h = tnb + n_pad / kTile;        // [wave][RT*32]: HEAD row terms 128*ra_head - 49024*D_head
-  // column sums (packed with the early-out) and tile bounds of the NEXT pair's image b, copied in by LDS-DMA while the
-  // current pair runs (no global load, hence no compiler vmcnt wait, at a pair boundary)
-  int* auxw = crow6h + kWaves * 64;         // [n_pad]
-  int* auxt = auxw + n_pad;                 // [n_tiles_img]
-  int4* winfo = (int4*)(auxt + n_tiles_img);       // [kPairWindow] {p, a, b, n1 | n2 << 16}: pairs with work, in order
-  int* wmeta = (int*)(winfo + kPairWindow);        // [0] entries in the window
-  int* crow6d = wmeta + 4;                         // [wave][RT*32]: full minus head row term (added when the early-out test fails)
-  constexpr int KH = head_steps_of(KS);
-#ifdef VC2_NO_EARLY
-  constexpr bool kEarlyOut = false;
-#else
-  constexpr bool kEarlyOut = KH < KS;
-#endif
-  const int d_head = min(d, KH * 32);
-
-#ifdef VC_EXP_STAMP
-  // diagnostic build: per-wave cycle totals over the workgroup's whole range (tools/stamp_matcher.py)
-  unsigned long long st_wait = 0, st_mfma = 0, st_epi = 0, st_init = 0, st_rowred = 0, st_final = 0;
-  const unsigned long long st_t0 = stamp();
-  unsigned long long st_tp = st_t0;
-#define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - st_tp; st_tp = t_; }
-#else
-#define VC_ST(acc_)
-#endif
-#ifdef VC_EXP_TRACE
-  // diagnostic build (with VC_EXP_STAMP, data without matches): per column tile and wave eight words
-  // {barrier arrival, release, MFMA begin, MFMA end, epilogue end, cut, -, -} into the workgroup's own (empty) match blocks
-  int trace_i = 0;
-#define VC_TR(k_, v_) { if ((threadIdx.x & 63) == 0 && trace_i >= 16 && trace_i < trace_n) trace[((size_t)trace_i * 8 + wave) * 8 + (k_)] = (uint32_t)(v_); }
-#else
-#define VC_TR(k_, v_)
-#endif
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
-  uint2* rscratch = (uint2*)(crow6 + kWaves * 64) + wave * kRowScratchEntries;  // this wave's slice
-  int* crow6_wave = crow6 + wave * 64;
-  int* crow6h_wave = crow6h + wave * 64;
-  int* crow6d_wave = crow6d + wave * 64;
-  const size_t img_stride = image_bytes(n_tiles_img, KS);
-  const size_t frag_bytes_img = (size_t)n_tiles_img * KS * kFragBytes;
-  const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
-
-  // this workgroup's range of the pair list
-  const int G = gridDim.x;
-  const int cid = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int lo = (int)(((long long)cid * n_pairs) / G);
-  const int hi = (int)(((long long)(cid + 1) * n_pairs) / G);
-
-  // ---- the pairs of the range that have work, kPairWindow at a time ------------------------------------------------
-  // One wave reads 64 pairs and their counts at once, writes zero counts for those with an empty image and lists the
-  // others in LDS; the per-pair description is then an LDS read.  (Read pair by pair with scalar loads, two dependent
-  // round trips sat between every two pairs.)  fetch() is called by all waves at the same points, between pairs.
-  int w_i = 0, w_n = 0, w_base = lo;   // wave-uniform
-  auto fetch = [&]() -> PairInfo {
-    PairInfo r;
-    r.p = hi; r.a = 0; r.n1 = 0; r.n2 = 0; r.n_ct = 0; r.n_pass = 0; r.b_frags = prepared;
-    while (w_i == w_n) {
-      if (w_base >= hi) return r;
-      __syncthreads();   // nobody is still reading the list this round replaces
-      if (wave == kWaves - 1) {
-        const int q = lane < kPairWindow ? w_base + lane : hi;
-        int a = 0, b = 0, n1 = 0, n2 = 0;
-        if (q < hi) {
-          a = pairs[2 * q]; b = pairs[2 * q + 1];
-          n1 = min(max(counts[a], 0), n_max); n2 = min(max(counts[b], 0), n_max);
-        }
-        const bool work = q < hi && n1 > 0 && n2 > 0;
-        if (q < hi && !work) out_counts[q] = 0;   // an empty image: nothing can match
-        const unsigned long long mask = __ballot(work);
-        if (work) winfo[__popcll(mask & ((1ull << lane) - 1ull))] = make_int4(q, a, b, n1 | (n2 << 16));
-        if (lane == 0) wmeta[0] = __popcll(mask);
-      }
-      __syncthreads();
-      w_n = __builtin_amdgcn_readfirstlane(wmeta[0]);
-      w_i = 0;
-      w_base = min(w_base + kPairWindow, hi);
-    }
-    const int4 e = winfo[w_i++];
-    r.p = __builtin_amdgcn_readfirstlane(e.x);
-    r.a = __builtin_amdgcn_readfirstlane(e.y);
-    const int b = __builtin_amdgcn_readfirstlane(e.z);
-    const int nn = __builtin_amdgcn_readfirstlane(e.w);
-    r.n1 = nn & 0xffff; r.n2 = nn >> 16;
-    r.n_ct = ceil_div(r.n2, kTile);
-    r.n_pass = ceil_div(r.n1, kWaves * 2 * kTile);
-    r.b_frags = prepared + (size_t)b * img_stride;
-    return r;
-  };
-  PairInfo cur = fetch();
-  if (cur.p >= hi) return;
-  PairInfo nxt = fetch();
-#ifdef VC_EXP_TRACE
-  uint32_t* trace = out_matches + (size_t)lo * n_max * 2;
-  const int trace_n = (int)(((size_t)(hi - lo) * n_max * 2) / 64);
-#endif
-
-  // ---- producer: a stream of column tiles over (pair, pass, tile), PF tiles ahead of the consumer ----------
-  // It sweeps the current pair's image b once per row pass, then moves on to the NEXT pair (whose description is
-  // already in registers), so the ring stays full across the pair boundary.  It never runs more than one pair
-  // ahead: a next pair shorter than the ring leaves it idle until the consumer gets there.
-  const int tpb = ns >= 6 ? kTilesPerBarrier : 1;   // a short ring (large blocks) keeps its depth: one tile per barrier
-  const int pf = ns - tpb;
-  const uint8_t* p_src = cur.b_frags;      // next tile to stage
-  const uint8_t* p_base = cur.b_frags;
-  int p_left = cur.n_ct, p_nct = cur.n_ct, p_sweeps = cur.n_pass;
-  bool p_on_next = false, p_active = true;
-  int prod_seq = 0, prod_slot = 0, cons_seq = 0, cons_slot = 0;
-  auto produce = [&]() {
-    if (p_active) {
-      stage_tile<KS, kProd2>(p_src, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane);
-      ++prod_seq;
-      if (++prod_slot == ns) prod_slot = 0;
-      p_src += KS * kFragBytes;
-      if (--p_left == 0) {
-        if (--p_sweeps > 0) {
-          p_src = p_base; p_left = p_nct;
-        } else if (!p_on_next && nxt.p < hi) {
-          p_on_next = true;
-          p_src = p_base = nxt.b_frags; p_left = p_nct = nxt.n_ct; p_sweeps = nxt.n_pass;
-        } else {
-          p_active = false;
-        }
-      }
-    }
-  };
-  for (int i = 0; i < pf; ++i) produce();
-
-  int* pair_flag = wave_count + kWaves;   // "some tile of the current pair was relevant"
-  // with the early-out the per-row word is the packed (head << 15 | tail) sum, else the plain row sum
-  const int rs_off = kEarlyOut ? n_pad : 0;
-  // Image b's column sums for pair X travel by LDS-DMA into the aux buffer, issued by one LATE wave (which has no other
-  // copy in flight, so its vmcnt(0) waits for exactly these) behind the first barrier of the pair before X — every
-  // thread has read that pair's own sums by then — and are read a whole pair later, after that wave's wait and the
-  // barrier that ends the pair in between.
-  constexpr int kAuxWave = kWaves / 2;
-  const u32 auxw_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(auxw));
-  const u32 auxt_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(auxt));
-  auto stage_aux = [&](const PairInfo& pi) {
-    if (wave == kAuxWave && pi.p < hi) {
-      int ln = lane;   // (laundered: lane-derived addresses are computed here, not carried across the tile loop)
-      asm volatile("" : "+v"(ln));
-      const uint8_t* sums = pi.b_frags + frag_bytes_img + (size_t)rs_off * 4;
-      const int pieces = ceil_div(pi.n_ct * kTile, 256);            // 1 KiB = 256 column words per piece
-      for (int i = 0; i < pieces; ++i)
-        glds16(sums + (size_t)i * 1024 + ln * 16, auxw_lds + (u32)(i * 1024));
-      if (kEarlyOut && ln < pi.n_ct)
-        glds4(pi.b_frags + frag_bytes_img + (size_t)2 * n_pad * 4 + ln * 4, auxt_lds);
-    }
-  };
-  stage_aux(cur);
-  if (wave == kAuxWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // The two waves of a SIMD (w and w + 4) run half a tile apart (see pair_kernel) on pairs that follow a pair with relevant
-  // similarities: there the epilogue is the long update path and the late half's runs under the early half's MFMAs (-6 %
-  // without).  On pairs without, the MFMA phase is 8 MFMAs and the epilogue a maximum and a ballot: all waves alike is
-  // 1.5-3 % faster.  `late` is set per pair (it must not change inside a pass: the late half's last epilogue is deferred).
-  const bool late_wave = wave >= kWaves / 2;
-  v4i afrag[RT][KS];
   int cur_a = -1, cur_tile0 = -1;
   int tna = 0;   // the larger tail norm bound of this wave's two row tiles (wave-uniform)
   int early_score = 0, early_probe = 0;   // gate of the early-out (wave-uniform, kept across pairs)
