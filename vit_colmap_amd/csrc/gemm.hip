@@ -1234,6 +1234,11 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
 #pragma unroll
           for (int ks = 0; ks < RD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
           __builtin_amdgcn_sched_barrier(0);
+#ifndef VC_MLP_NO_PRIO_A
+          // the fc1 role is the longer one (its GELU slices and x load ride in this phase): it gets the issue priority on
+          // its SIMD — 238 -> 230 us per layer; raising the fc2 role instead loses
+          __builtin_amdgcn_s_setprio(1);
+#endif
           if (i > 0) {
 #pragma unroll
             for (int ks = 0; ks < XKS; ++ks) {
@@ -1253,6 +1258,9 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
             }
           }
         }
+#ifndef VC_MLP_NO_PRIO_A
+        __builtin_amdgcn_s_setprio(0);
+#endif
         hprev = hacc;
         MS(3)
         if (++chunk == n_chunks) { chunk = 0; tile += G; }
@@ -1294,6 +1302,9 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           v8bf wf[24];
 #pragma unroll
           for (int q = 0; q < RD; ++q) wf[q] = *(const v8bf*)(st2 + q * 1024);
+#ifdef VC_MLP_PRIO_B
+          __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
           for (int q = 0; q < 24; ++q) {
             oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
@@ -1302,6 +1313,9 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
               issue_piece(nc1, nc2, slot ^ 1, (q - VC_MLP_ISSUE0) / VC_MLP_ISSUE_STEP);   // (see the A waves)
           }
         }
+#ifdef VC_MLP_PRIO_B
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef VC_MLP_STAMP
         asm volatile("s_nop 0" :: "v"(oacc[11]));
 #endif
