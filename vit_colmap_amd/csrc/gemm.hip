@@ -1027,6 +1027,9 @@ constexpr int M2OffG = M2OffTrB + 4 * XChunk;        // activation hand-off: [2 
 constexpr int M2Lds = M2OffG + 2 * 4 * 2048;         // 96 + 16 + 16 + 16 + 16 = 160 KiB
 static_assert(M2Lds <= 160 * 1024, "fused MLP: LDS budget");
 
+#ifndef VC_MLP_RD
+#define VC_MLP_RD 6          // weight fragments read ahead of the MFMA that uses them
+#endif
 #ifndef VC_MLP_ISSUE0
 #define VC_MLP_ISSUE0 1       // first MFMA behind which a piece of the next stage is issued ...
 #define VC_MLP_ISSUE_STEP 3   // ... and the distance to the next one (sweep: 1+3k 228 us, 1+2k 229, 0+k 233, 1+4k 235)
@@ -1229,7 +1232,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           }
         }
         {
-          constexpr int RD = 6;
+          constexpr int RD = VC_MLP_RD;
           v8bf wf[XKS];
 #pragma unroll
           for (int ks = 0; ks < RD; ++ks) wf[ks] = *(const v8bf*)(st + ks * 1024);
@@ -1298,7 +1301,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
         const v8bf g_s0 = *(const v8bf*)gb, g_s1 = *(const v8bf*)(gb + 1024);
         const uint8_t* st2 = lds + slot * MStage + XStage + lane * 16;
         {
-          constexpr int RD = 6;
+          constexpr int RD = VC_MLP_RD;
           v8bf wf[24];
 #pragma unroll
           for (int q = 0; q < RD; ++q) wf[q] = *(const v8bf*)(st2 + q * 1024);
