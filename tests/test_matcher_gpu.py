@@ -162,7 +162,7 @@ def test_persistent_ranges_more_pairs_than_cus(n_images, n_max, d, kind):
     assert_batch_equal(desc, counts, shuffled)
 
 
-@pytest.mark.parametrize("n_images,n_max,d", [(40, 512, 384), (36, 300, 256)])
+@pytest.mark.parametrize("n_images,n_max,d", [(40, 512, 384), (36, 300, 256), (44, 200, 128), (30, 700, 64)])
 def test_sparse_pairs_with_planted_matches(n_images, n_max, d):
     """Mostly non-matching descriptors (every tile cut short by the early-out, two column tiles per barrier) with
     descriptors planted in some images: those pairs fail the head test on a few tiles (the restart-free continuation),
