@@ -69,7 +69,12 @@ int vc_prepare_descriptors(const uint8_t* desc, const int32_t* counts, int n_ima
  * angle + ratio tests, optional cross check; writes the matches ordered by row index to
  * out_matches[p][0..out_counts[p]) as (row in a, row in b) uint32 pairs.
  * out_matches: [n_pairs][n_max][2] uint32; out_counts: [n_pairs] int32.
+ * out_counts[p] == VC_COUNT_SELFCHECK_FAILED (-1): the persistent kernel's consistency check failed for that pair — the
+ * waves of its workgroup disagreed on the tile-ring cursors, which the source makes identical by construction (a
+ * toolchain fault of this kind is documented in profiles/r03_matcher_looped_miscompile.md); the pair's list is undefined.
+ * Never produced by a correct build: callers treat it as an error (the Python host raises HipLibraryError).
  */
+#define VC_COUNT_SELFCHECK_FAILED (-1)
 int vc_match_pairs_u8(const void* prepared, const int32_t* counts, int n_images, int n_max, int d,
                       const int32_t* pairs, int n_pairs, float max_ratio, float max_distance,
                       int cross_check, uint32_t* out_matches, int32_t* out_counts,
@@ -305,8 +310,9 @@ int vc_linear_xs_bf16(const void* x, const void* weight_tiled, const float* bias
 /*
  * GELU table for VC_EPI_GELU (optional): with a table the epilogue evaluates the GELU as the standard bf16
  * pipeline does — on the bf16-ROUNDED pre-activation, result rounded to bf16, bit for bit
- * bf16(0.5 x (1 + erff(x / sqrt 2))) — by an LDS lookup (integer work, which overlaps with the matrix pipe on
- * gfx950 where float VALU work does not) instead of ~150 float instructions per 32x32 block.  Without a table
+ * bf16(0.5 x (1 + erff(x / sqrt 2))) — by an LDS lookup: a handful of integer instructions and one ds_read_u16 per value instead of
+ * ~150 float instructions per 32x32 block (fewer issue slots beside the MFMAs; float and integer VALU overlap
+ * with the matrix pipe alike, profiles/r02_overlap_probe.md).  Without a table
  * (NULL) the GELU is evaluated in float32 on the unrounded pre-activation.  vc_gelu_table_bytes() bytes,
  * 16-byte aligned, filled once by vc_gelu_table_bf16; used when n_out * 4 + table <= 16 KiB.
  */

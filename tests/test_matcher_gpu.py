@@ -14,18 +14,23 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+SENTINEL = -77777   # out_counts is pre-filled with it: a count the kernel never wrote cannot pass for a result
+
+
 def run_batch(desc, counts, pairs, **kw):
     from vit_colmap_amd.matching import match_pairs, prepare_descriptors
 
     n_images, n_max, d = desc.shape
     prepared = prepare_descriptors(dev(desc), dev(counts))
-    m, c = match_pairs(prepared, dev(counts), n_images, n_max, d, dev(pairs), **kw)
+    out_counts = torch.full((len(pairs),), SENTINEL, dtype=torch.int32, device="cuda")
+    m, c = match_pairs(prepared, dev(counts), n_images, n_max, d, dev(pairs), out_counts=out_counts, **kw)
     torch.cuda.synchronize()
     return m.cpu().numpy().view(np.uint32), c.cpu().numpy()
 
 
 def assert_batch_equal(desc, counts, pairs, **kw):
     gm, gc = run_batch(desc, counts, pairs, **kw)
+    assert not np.any(gc == SENTINEL), f"counts never written for pairs {np.nonzero(gc == SENTINEL)[0][:10]}"
     om, oc, _ = c_oracle.match_pairs(desc, counts, pairs, **kw)
     assert np.array_equal(gc, oc), f"match counts differ: {np.nonzero(gc != oc)[0][:10]}"
     for p in range(len(pairs)):
@@ -89,6 +94,31 @@ def test_match_pairs_batch_exact(kind, d):
         assert gc.sum() > 1000            # the accept path is really exercised
     if kind == "full":
         assert gc.sum() == 0              # saturated similarities are all rejected
+
+
+@pytest.mark.parametrize("d", [384, 256, 200])
+def test_match_pairs_bright_rows_packed_sums(d):
+    """Arbitrary uint8 input the C ABI accepts: rows whose bytes beyond the first 128 dimensions sum to more than
+    2^15 (the packed head / tail row sums gave the tail 15 bits) against sparse rows, so that the
+    similarities stay below saturation and planted matches pass the angle tests."""
+    rs = np.random.RandomState(d)
+    n = 96
+    bright = rs.randint(150, 200, (n, d)).astype(np.uint8)
+    special = np.stack([rs.permutation(d)[:4] for _ in range(n)])      # 4 dimensions per row that hold 255
+    for i in range(n):
+        bright[i, special[i]] = 255
+    if d == 384:   # the tail of the packed word: dimensions 128.. (KS = 12, head of 4 k-steps)
+        assert bright[:, 128:].astype(np.int64).sum(axis=1).min() >= 1 << 15
+    sparse = np.zeros((n, d), np.uint8)
+    perm = rs.permutation(n)
+    for j in range(n):
+        sparse[j, special[perm[j]]] = 250                              # s = 255000 with its partner, ~175000 otherwise
+    desc = np.ascontiguousarray(np.stack([bright, sparse, bright[::-1], sparse[perm]]))
+    counts = np.full(4, n, np.int32)
+    pairs = np.array([[0, 1], [1, 0], [2, 1], [1, 2], [0, 3], [0, 2], [1, 3]], np.int32)
+    gc = assert_batch_equal(desc, counts, pairs)
+    assert gc[0] == n and gc[1] == n and gc[4] == n                    # every planted partner is found
+    assert_batch_equal(desc, counts, pairs, max_ratio=0.95, max_distance=1.2)
 
 
 def test_match_pairs_ragged_counts_and_empty_images():
@@ -185,6 +215,29 @@ def test_sparse_pairs_with_planted_matches(n_images, n_max, d):
     assert gc.sum() > 100 and (gc == 0).sum() > len(pairs) // 2            # both kinds of pairs are present
     perm = rs.permutation(len(pairs))
     assert_batch_equal(desc, counts, np.ascontiguousarray(pairs[perm]), max_distance=1.1)   # no runs of image a
+
+
+@pytest.mark.parametrize("d", [384, 256, 128])
+@pytest.mark.parametrize("n_long", [8 * 32, 16 * 32 - 5, 64 * 32])
+def test_short_image_a_against_long_image_b(d, n_long):
+    """image a with 1 / 2 / 31 rows (seven of the eight waves own no live row, and the wave that does
+    fails the early-out test while its SIMD partners pass it) against images of 8 / 16 / 64 column tiles, on both
+    ring modes (D = 128: two tiles per barrier; D = 256 / 384 at 2048 rows: one), counts pre-filled with a sentinel."""
+    n_short = [1, 2, 31]
+    n_images = 9
+    counts = np.array(n_short + [n_long, n_long - 7, n_long, 1, 33, n_long], np.int32)
+    desc, counts = image_set(n_long + d, n_images, n_long, d, kind="scene", counts=counts, noise=0.05)
+    # every short image against every long one, in both orders, short-short pairs in between
+    pairs = [(a, b) for a in range(3) for b in range(3, 9)] + [(b, a) for a in range(3) for b in (3, 5, 8)]
+    pairs += [(0, 1), (0, 2), (1, 2), (6, 0), (6, 7)]
+    pairs = np.array(pairs, np.int32)
+    gc = assert_batch_equal(desc, counts, pairs)
+    assert gc.sum() > 20
+    # few pairs: every workgroup holds exactly one (the producer stays active through its only pair)
+    assert_batch_equal(desc, counts, np.ascontiguousarray(pairs[:7]))
+    # and "vit" rows (no relevant tile at all: two tiles per barrier from the first round on)
+    desc2, _ = image_set(n_long + d + 1, n_images, n_long, d, kind="vit", counts=counts)
+    assert_batch_equal(desc2, counts, pairs)
 
 
 @pytest.mark.parametrize("n_pairs", [1, 2, 7, 255, 256, 257, 263])

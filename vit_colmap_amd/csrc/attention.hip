@@ -56,8 +56,8 @@ __device__ inline uint32_t v_off(int key, int byte_in_row) {
 // is only an integer test "some score exceeds the running maximum by more than kLazyTh" (float bit patterns of
 // positive numbers order as integers).  Any reference value gives the same softmax after normalisation; the
 // exact maximum is re-established (standard rescale) when the test fires, so probabilities stay <= 2^kLazyTh.
-// float32 VALU work does not overlap with the matrix pipe on gfx950 (tools/overlap_probe.hip): removing one of the
-// five float issue slots per score is a direct saving.
+// The softmax over-subscribes the SIMD's issue port (~11 slots per MFMA gap against the ~6 that hide,
+// profiles/r02_overlap_probe.md): removing one of the five VALU issue slots per score is a direct saving.
 constexpr float kLazyTh = 6.0f;
 #ifdef VC_ATTN_STAMP
 // diagnostic build only (tools/stamp_attn.py): shader-clock totals per wave and phase, written over the wave's first output row

@@ -56,8 +56,15 @@ __host__ __device__ inline int ksteps_of(int d) { return ceil_div(d, 32); }
 #endif
 __host__ __device__ constexpr int head_steps_of(int ks) { return ks == 12 ? VC2_KH12 : (ks == 8 ? 4 : ks); }   // multiples of BWindow::NB
 // prepared image = fragments | row sums int32 [n_pad] | packed head / tail row sums int32 [n_pad] | per-tile tail norm bounds int32 [n_tiles]
-//   packed word   = (head << 15) | tail: sums of the row's bytes over the first head_steps_of(ks) * 32 dimensions and over the rest
+//   packed word   = (head << 16) | tail: sums of the row's bytes over the first head_steps_of(ks) * 32 dimensions and over the rest
+//                   (field widths: packed_sums_fit() below, asserted for every length the early-out kernels are built for)
 //   tail norm     = max over the tile's 32 rows of ceil(sqrt(sum of squared bytes over the remaining dimensions))
+__host__ __device__ constexpr bool packed_sums_fit(int ks) {   // head < 2^15 (the word stays positive), tail < 2^16
+  return head_steps_of(ks) == ks || (255 * 32 * head_steps_of(ks) < (1 << 15) && 255 * 32 * (ks - head_steps_of(ks)) < (1 << 16));
+}
+static_assert(packed_sums_fit(8) && packed_sums_fit(12), "head / tail row sums must fit the packed word (VC2_KH12 is a build parameter)");
+__host__ __device__ inline int packed_head(int word) { return word >> 16; }
+__host__ __device__ inline int packed_tail(int word) { return word & 0xffff; }
 __host__ __device__ inline size_t image_bytes(int n_tiles, int ks) {
   return (size_t)n_tiles * ks * kFragBytes + (size_t)n_tiles * kTile * sizeof(int32_t) * 2 + (size_t)n_tiles * sizeof(int32_t);
 }
@@ -177,8 +184,8 @@ __global__ void prepare_kernel(const uint8_t* __restrict__ desc, const int32_t* 
       }
     }
     rowsum[c] = sum;
-    // the early-out kernels read ONE word per row: head sum and tail sum packed (head <= 255 * 256 < 2^16, tail <= 255 * 128 < 2^15)
-    rowsum_head[c] = head_steps_of(ks) < ks ? ((head << 15) | (sum - head)) : head;
+    // the early-out kernels read ONE word per row: head sum and tail sum packed (packed_sums_fit)
+    rowsum_head[c] = head_steps_of(ks) < ks ? ((head << 16) | (sum - head)) : head;
     int tn = (int)ceil(sqrt((double)ss));
     while ((long long)tn * tn < ss) ++tn;   // an upper bound of the Euclidean norm of the tail, whatever sqrt rounded to
     atomicMax(&s_tn, tn);
@@ -692,110 +699,6 @@ __device__ __forceinline__ bool epilogue_phase2(const v16i (&acc)[2], u32 (&rbes
   return hit;
 }
 
-// ---------------------------------------------------------------------------------------
-// In-wave pipelining (RT = 2).  tools/overlap_probe.hip: a SIMD has ONE vector issue port — an MFMA takes it
-// for 8 of its 32 cycles, an ordinary VALU instruction for 4 — and the matrix pipe runs behind it.  Work
-// that alternates MFMA and VALU inside one wave costs max(32 N_mfma, 8 N_mfma + 4 N_valu); an MFMA cluster
-// in one wave beside a VALU cluster in its SIMD partner (the staggered halves this kernel used before) costs
-// close to the SUM, because back-to-back MFMAs keep the port.  So each wave interleaves: while the 12 MFMAs
-// of row tile 0 of column tile t issue, the relevance pass of row tile 1 of column tile t-1 runs in the
-// gaps (and vice versa for the second half); the two accumulator tiles ping-pong, no extra registers.
-// ---------------------------------------------------------------------------------------
-struct RelevancePass {   // pass 1 of the epilogue for one 32x32 tile, cut into steps
-  v4i cr[4];
-  int m;
-};
-// step 0: first row-term reads; steps 1..4: similarities of registers 4q..4q+3 and their running maximum
-// (each step reads the row terms of the next one: two of the four vectors are live)
-template <int KS>
-__device__ __forceinline__ void relevance_steps(int slot_i, const v16i& a, const int* rterm_rt, int h, int ct,
-                                                RelevancePass& st) {
-#pragma unroll
-  for (int sidx = 0; sidx < 5; ++sidx) {
-    if ((sidx * KS) / 5 != slot_i) continue;
-    if (sidx == 0) {
-      st.m = -1;
-      st.cr[0] = *(const v4i*)(rterm_rt + 4 * h);
-    } else {
-      const int q = sidx - 1;
-      if (q + 1 < 4) st.cr[q + 1] = *(const v4i*)(rterm_rt + 8 * (q + 1) + 4 * h);
-      const int v0 = a[4 * q + 0] + st.cr[q][0] + ct, v1 = a[4 * q + 1] + st.cr[q][1] + ct;
-      const int v2 = a[4 * q + 2] + st.cr[q][2] + ct, v3 = a[4 * q + 3] + st.cr[q][3] + ct;
-      st.m = max(max(st.m, max(v0, v1)), max(v2, v3));
-    }
-  }
-}
-
-// KS MFMAs of one row tile against the column tile at `src`.  The first RD B fragments arrive in `bf_io`
-// (read by the caller or by the previous half), the rest are read RD steps ahead; with NEXT the last RD
-// steps read the first fragments again for the half that follows on the same column tile, so only the
-// first half of a tile exposes the LDS latency.  `slice(i)` is issued after the i-th MFMA (sched_barrier
-// pins the interleave; the compiler places the counted waits).
-constexpr int kRd = 2;
-template <int KS, bool NEXT, typename Slice>
-__device__ __forceinline__ void mfma_half(const v4i (&af)[KS], v16i& acc, const uint8_t* src,
-                                          v4i (&bf_io)[kRd], Slice slice) {
-  constexpr int RD = KS < kRd ? KS : kRd;
-  v4i bf[KS];
-#pragma unroll
-  for (int i = 0; i < RD; ++i) bf[i] = bf_io[i];
-#pragma unroll
-  for (int i = 0; i < KS; ++i) {
-    if (i == 0) {
-      const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[0], zero, 0, 0, 0);
-    } else {
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[i], acc, 0, 0, 0);
-    }
-    if (i + RD < KS) bf[i + RD] = *(const v4i*)(src + (i + RD) * kFragBytes);
-    else if (NEXT) bf_io[i + RD - KS] = *(const v4i*)(src + (i + RD - KS) * kFragBytes);
-    slice(i);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// pass 2 of the epilogue for one row tile (see epilogue_phase): top-2 updates of the 16 rows a lane holds,
-// the lane's column candidates merged into LDS.  Returns whether the tile held a relevant similarity.
-template <bool FUSED>
-__device__ __forceinline__ bool update_tile(const v16i& a, u32 (&rbest)[16], u32 (&rsec)[16], const int* rterm_rt,
-                                            int ct, int jt, int rt, int c, int h, u32 row_base, int s_low,
-                                            unsigned long long* colbest, u32* colsecond) {
-  const int* rterm2 = rterm_rt;
-  asm volatile("" : "+v"(rterm2));
-  const u32 jcode = 63u - (u32)jt;
-  u32 cb = 0, cs2 = 0;
-  int m = -1;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const v4i cr = *(const v4i*)(rterm2 + 8 * q + 4 * h);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * q + i;
-      const int v = a[r] + cr[i] + ct;
-      m = max(m, v);
-      const u32 rk = ((u32)v << 6) | jcode;
-      rsec[r] = umed3(rbest[r], rsec[r], rk);
-      rbest[r] = umax(rbest[r], rk);
-      if (FUSED) {
-        const u32 ck = ((u32)v << 6) | (u32)(63 - (rt * kTile + (r & 3) + 8 * (r >> 2)));
-        cs2 = umed3(cb, cs2, ck);
-        cb = umax(cb, ck);
-      }
-    }
-  }
-  if (FUSED && cb != 0) {
-    const int j = jt * kTile + c;
-    const u32 sb = cb >> 6;
-    const u32 grow = row_base + (63u - (cb & 63u)) + 4u * h;
-    const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
-    const unsigned long long old = atomicMax(&colbest[j], key);
-    u32 cand = key > old ? (u32)(old >> 32) : sb;
-    cand = umax(cand, cs2 >> 6);
-    atomicMax(&colsecond[j], cand);
-  }
-  return __any(m > s_low);
-}
-
 template <int KS, int RT, bool FUSED>
 __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
     const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
@@ -854,12 +757,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
   const int n_ct = ceil_div(n2, kTile);  // column tiles of b that hold valid rows
   const int n_pass = ceil_div(n1, kRowsPerPass);
   const int total = n_pass * n_ct;       // tiles consumed, in order (pass, jt)
-#ifdef VC_INWAVE_LOOP
-  // RT = 2 consumes two tiles per barrier, so a refill may only target the two slots of the previous iteration
-  const int pf = RT == 2 ? ns - 2 : ns - 1;
-#else
   const int pf = ns - 1;
-#endif
 
   if (total == 0) {  // an empty image: nothing can match (uniform exit)
     if (FUSED) { if (tid == 0) out_counts[p] = 0; }
@@ -946,81 +844,6 @@ __global__ __launch_bounds__(kThreads, 2) void pair_kernel(
       }
     };
 
-#ifdef VC_INWAVE_LOOP
-    if constexpr (RT == 2) {
-      // ---- in-wave pipelined loop: see the comment above RelevancePass ----------------------------------
-      int ct_prev = 0;
-#ifdef VC_EXP_STAMP
-      unsigned long long sw = 0, sm = 0, se = 0;
-      const unsigned long long t_begin = stamp();
-      unsigned long long tp = t_begin;
-#define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - tp; tp = t_; }
-#else
-#define VC_ST(acc_)
-#endif
-      // one column tile: both halves, and the refill of one ring slot
-      auto process_tile = [&](int jt, const uint8_t* slot) {
-        const int ct = cterm[jt * kTile + c];
-        const uint8_t* src = slot + lane * 16;
-        RelevancePass p1;
-        v4i bf_io[kRd];
-#pragma unroll
-        for (int i = 0; i < (KS < kRd ? KS : kRd); ++i) bf_io[i] = *(const v4i*)(src + i * kFragBytes);
-        __builtin_amdgcn_sched_barrier(0);
-        // first half: row tile 0 of column tile jt  ||  relevance pass of row tile 1 of column tile jt-1
-        // (jt = 0: the accumulators are the zeros written above; an unreachable threshold neutralises it)
-        mfma_half<KS, true>(afrag[0], acc[0], src, bf_io, [&](int i) {
-          if (i == (KS > 1 ? 1 : 0)) produce();
-          relevance_steps<KS>(i, acc[1], crow6_wave + kTile, h, ct_prev, p1);
-        });
-        VC_ST(sm)
-        if (dense[1] || __any(p1.m > (jt > 0 ? s_low : 0x7fffffff)))
-          dense[1] = update_tile<FUSED>(acc[1], rbest[1], rsec[1], crow6_wave + kTile, ct_prev, jt - 1, 1, c, h,
-                                        row_base, s_low, colbest, colsecond);
-        VC_ST(se)
-        // second half: row tile 1 of column tile jt  ||  relevance pass of row tile 0 of column tile jt
-        mfma_half<KS, false>(afrag[1], acc[1], src, bf_io, [&](int i) { relevance_steps<KS>(i, acc[0], crow6_wave, h, ct, p1); });
-        VC_ST(sm)
-        if (dense[0] || __any(p1.m > s_low))
-          dense[0] = update_tile<FUSED>(acc[0], rbest[0], rsec[0], crow6_wave, ct, jt, 0, c, h, row_base, s_low,
-                                        colbest, colsecond);
-        VC_ST(se)
-        ct_prev = ct;
-      };
-      // Two column tiles per workgroup barrier: the waves of a SIMD drift apart by hundreds of cycles per
-      // tile (the younger one loses issue arbitration), and every barrier turns that drift into idle time.
-      for (int jt = 0; jt < n_ct; jt += 2) {
-        const bool two = jt + 1 < n_ct;
-        // the later of the tiles consumed in this iteration must have landed
-        wait_tile<KS>(wave, prod_seq - cons_seq - (two ? 2 : 1));
-        wg_barrier();
-        const uint8_t* slot0 = ring + (size_t)cons_slot * KS * kFragBytes;
-        if (++cons_slot == ns) cons_slot = 0;
-        const uint8_t* slot1 = ring + (size_t)cons_slot * KS * kFragBytes;
-        if (two && ++cons_slot == ns) cons_slot = 0;
-        cons_seq += two ? 2 : 1;
-        VC_ST(sw)
-        process_tile(jt, slot0);
-        if (two) process_tile(jt + 1, slot1);
-      }
-#ifdef VC_EXP_STAMP
-      if (FUSED && lane == 0 && pass == 0) {
-        uint32_t* dbg = out_matches + ((size_t)p * n_max + (n_max - 64)) * 2 + wave * 8;
-        dbg[0] = (uint32_t)sw; dbg[1] = (uint32_t)sm; dbg[2] = (uint32_t)se;
-        dbg[3] = (uint32_t)(tp - t_begin); dbg[4] = (uint32_t)(t_begin - t_kernel_start);
-      }
-#endif
-#undef VC_ST
-      {  // row tile 1 of the last column tile has no MFMAs to ride under
-        RelevancePass p1;
-#pragma unroll
-        for (int i = 0; i < KS; ++i) relevance_steps<KS>(i, acc[1], crow6_wave + kTile, h, ct_prev, p1);
-        if (dense[1] || __any(p1.m > s_low))
-          dense[1] = update_tile<FUSED>(acc[1], rbest[1], rsec[1], crow6_wave + kTile, ct_prev, n_ct - 1, 1, c, h,
-                                        row_base, s_low, colbest, colsecond);
-      }
-    } else
-#endif
     {
     // Staggered halves (late = waves 4-7): one loop, the epilogue shared, only the MFMA phase
     // placed before or after it.  The late half runs the epilogue of tile jt-1; for jt = 0 that
@@ -1389,7 +1212,11 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
   for (int i = 0; i < pf; ++i) produce();
 
   int* pair_flag = wave_count + kWaves;   // "some tile of the current pair was relevant"
-  // with the early-out the per-row word is the packed (head << 15 | tail) sum, else the plain row sum
+  // Cursor check: prod_seq / cons_seq exist once per wave (SGPRs) and must agree across the workgroup — `two`, the slot
+  // indices and the counted waits are all derived from them.  Every wave folds its pair of cursors into a max and a min
+  // word at the end of a pair's tile loop; if they differ the pair's count is written as -1 instead of a match count.
+  int* cursor_chk = pair_flag + 1;        // [2]: max, min over the waves
+  // with the early-out the per-row word is the packed (head << 16 | tail) sum, else the plain row sum
   const int rs_off = kEarlyOut ? n_pad : 0;
   // Image b's column sums for pair X travel by LDS-DMA into the aux buffer, issued by one LATE wave (which has no other
   // copy in flight, so its vmcnt(0) waits for exactly these) behind the first barrier of the pair before X — every
@@ -1442,7 +1269,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     // (columns 0..511 come from the register fetched during the previous pair: the load's latency was 2 k cycles
     // of every pair when it sat here)
     auto init_column = [&](int j, int word) {
-      const int head = kEarlyOut ? (word >> 15) : 0, total = kEarlyOut ? head + (word & 0x7fff) : word;
+      const int head = kEarlyOut ? packed_head(word) : 0, total = kEarlyOut ? head + packed_tail(word) : word;
       if (kEarlyOut) cterm_h[j] = 128 * head + 32640 * d_head;
       cterm[j] = 128 * total + 32640 * d;
       col[j].best = 0ull;
@@ -1456,7 +1283,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     for (int j = tidp; j < n_ct * kTile; j += kThreads) init_column(j, auxw[j]);
     if (kEarlyOut && tidp < n_ct) tnb[tidp] = auxt[tidp];
     for (int i = tidp; i < n1; i += kThreads) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
-    if (tidp == 0) *pair_flag = 0;
+    if (tidp == 0) { *pair_flag = 0; cursor_chk[0] = (int)0x80000000; cursor_chk[1] = 0x7fffffff; }
     bool pair_hit = false;   // some tile of this wave held a relevant similarity
 
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -1471,7 +1298,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         // wave-private and its LDS operations execute in order
         {
           const int word = a_rowsum[rs_off + tile0 * kTile + lane];
-          const int head = kEarlyOut ? (word >> 15) : 0, total = kEarlyOut ? head + (word & 0x7fff) : word;
+          const int head = kEarlyOut ? packed_head(word) : 0, total = kEarlyOut ? head + packed_tail(word) : word;
           crow6_wave[lane] = 128 * total - 49024 * d;
           if (kEarlyOut) {
             crow6h_wave[lane] = 128 * head - 49024 * d_head;
@@ -1553,8 +1380,11 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
         VC_TR(1, st_tp)
         const int n_sub = two ? 2 : 1;
         {
-          // (The second tile as a second trip through ONE copy of this body — a loop that is not unrolled — left out_counts
-          // unwritten for pairs with few rows and eight or more column tiles: the build is kept straight-line.)
+          // (Straight-line on purpose.  As a second trip through ONE copy of this body hipcc 7.2.0 gave the SGPR pair that
+          // carries produce()'s p_active across the back edge to the early-out gate as well: waves on the variant with the
+          // test then saw the producer inactive, the waves of a workgroup disagreed on `two` and barriers paired up wrongly —
+          // profiles/r03_matcher_looped_miscompile.md, tools/repro/looped_sub.patch.  The cursor check at the end of every pair
+          // (below) turns that class of fault into an error code instead of a wrong match list.)
           const uint8_t* slot = ring + (size_t)cons_slot * KS * kFragBytes;
           if (++cons_slot == ns) cons_slot = 0;
           ++cons_seq;
@@ -1624,13 +1454,19 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
     int tidf = tid;   // (as tidp: the finalisation's addresses are computed here, not carried through the tile loop)
     asm volatile("" : "+v"(tidf));
     if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
+    if (lane == 0) {
+      const int cursors = (cons_seq & 0xffff) | ((prod_seq & 0x7fff) << 16);
+      atomicMax(&cursor_chk[0], cursors);
+      atomicMin(&cursor_chk[1], cursors);
+    }
     __syncthreads();
     const int pair_was_hit = __builtin_amdgcn_readfirstlane(*pair_flag);
+    const bool cursors_agree = __builtin_amdgcn_readfirstlane(cursor_chk[0]) == __builtin_amdgcn_readfirstlane(cursor_chk[1]);
     pairs_dense = pair_was_hit != 0;   // (workgroup-uniform: every wave reads the same word behind the barrier)
     if (pair_was_hit == 0) {
       // No tile of the pair held a similarity above the relevance threshold: every row's best stays below what the
       // angle test accepts, the match list is empty and nothing of the finalisation has to run.
-      if (tidf == 0) out_counts[p] = 0;
+      if (tidf == 0) out_counts[p] = cursors_agree ? 0 : VC_COUNT_SELFCHECK_FAILED;
     } else {
     // ---- angle + ratio tests, cross check, ordered compaction ---------------------------------------------------
     if (cross_check) {
@@ -1670,7 +1506,7 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
       base += chunk_total;
       __syncthreads();
     }
-    if (tidf == 0) out_counts[p] = base;
+    if (tidf == 0) out_counts[p] = cursors_agree ? base : VC_COUNT_SELFCHECK_FAILED;
     }
     // the next pair's column sums (copied in during this pair) have landed before the barrier that lets it start
     if (wave == kAuxWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1699,550 +1535,6 @@ __global__ __launch_bounds__(kThreads, 2) void pair2_kernel(
 #undef VC_ST
 #undef VC_TR
 }
-
-// ---------------------------------------------------------------------------------------
-// EXPERIMENT, not in the shipped library (built only with -DVC_PAIR3_EXPERIMENT by tools/build_variants.sh):
-// pair3_kernel, ONE wave per SIMD.  Measured on MI355X (tools/ablate_matcher.sh, 200 x 512 x 384): 9.9 M pairs/s
-// against pair2_kernel's 12.6 M (dense data 5.5 M vs 7.1 M) — with nothing else resident on the SIMD, the ~150 cycles
-// a wave is held per LDS-DMA piece it issues (3 per column tile), the barrier skew and the LDS latency behind a
-// 6-deep fragment window are all exposed, which costs more than the in-wave pipelining gains.  It is bit-exact only
-// with wait states in front of every MFMA (-DVC3_NOP): at D = 384 the allocator keeps one A fragment in VGPRs and
-// copies it into an AGPR right before the asm MFMA that reads it (2 wait states missing).  Kept for the record of
-// what was tried; vc_match_pairs_u8 never launches it.
-#ifdef VC_PAIR3_EXPERIMENT
-// pair3_kernel: ONE wave per SIMD (four-wave workgroups, up to 512 registers per lane)
-// ---------------------------------------------------------------------------------------
-// Stamps of pair2_kernel (tools/stamp_matcher.py) showed where its 256-register waves lose time: a wave alone on its
-// SIMD issues an MFMA every ~50 cycles instead of every 32, because its B fragments are requested only one group
-// (128 pipe cycles) ahead while an LDS read takes ~200 under load, and there is no register left for a deeper
-// look-ahead; the two waves of a SIMD cover for each other only where their MFMA phases happen to overlap.
-// With one wave per SIMD the register file is twice as large, and everything is pipelined INSIDE the wave
-// (MI355X_MICROARCH.md, "one wave per SIMD (512-register kernel)": <= 5 single-issue instructions hide per MFMA gap):
-//   * each wave owns FOUR 32-row tiles of image a (192 fragment registers at D = 384): 4 x 128 = 512 rows per pass;
-//   * B fragments stream from the LDS ring through an 8-deep register window (256 pipe cycles of look-ahead) that
-//     runs across row tiles and across column tiles (a tile is known to have landed one barrier early);
-//   * the accumulators ping-pong between two sets: while the 12 MFMAs of row tile r issue, the epilogue of row tile
-//     r - 1 (the last one of the previous column tile for r = 0) runs in their gaps — relevance test in the first
-//     half, and only if it fires the top-2 updates in the second half;
-//   * column candidates of the four row tiles of a column tile accumulate in two registers; one pair of LDS atomics
-//     per lane and column tile.
-// Arithmetic, LDS state, ranges of pairs per workgroup, ring across pairs, table-based finalisation: as pair2_kernel.
-constexpr int kW3 = 4;                       // waves per workgroup
-constexpr int kT3 = kW3 * 64;
-constexpr int kRT3 = 4;                      // row tiles per wave
-// B fragments in flight per wave (register window); it divides 4 KS so that the window registers are addressed
-// statically, and at D = 384 it leaves the 192 fragment + 32 accumulator registers room in the 256 AGPRs
-template <int KS> struct Window3 { static constexpr int PD = (KS == 12) ? 6 : 8; };
-
-__host__ __device__ inline size_t lds_fixed_bytes3(int n_pad) {
-  return (size_t)n_pad * (8 + 4 + 4 + 4 + 12) + kW3 * kRT3 * kTile * 4 + kW3 * kRowScratchBytes + 64;
-}
-inline int plan_slots3(int ks, int n_pad) {
-  const long avail = (long)kLdsBytes - (long)lds_fixed_bytes3(n_pad);
-  long ns = avail / ((long)ks * kFragBytes);
-  if (ns > kMaxSlots) ns = kMaxSlots;
-  return ns >= 4 ? (int)ns : 0;
-}
-
-template <int KS>
-struct Producer3 {
-  static constexpr int M = (KS + kW3 - 1) / kW3;
-  static constexpr int NP = KS / M;
-  static_assert(NP * M == KS && NP <= kW3, "pieces must divide evenly over the producer waves");
-};
-
-template <int KS>
-__device__ __forceinline__ void stage_tile3(const uint8_t* __restrict__ tile_src, u32 slot_lds, int wave, int lane) {
-  if (wave < Producer3<KS>::NP) {
-#pragma unroll
-    for (int m = 0; m < Producer3<KS>::M; ++m) {
-      const int kk = wave * Producer3<KS>::M + m;
-      glds16(tile_src + kk * kFragBytes + lane * 16, slot_lds + kk * kFragBytes);
-    }
-  }
-}
-
-template <int KS>
-__device__ __forceinline__ void wait_tile3(int wave, int younger) {
-  constexpr int M = Producer3<KS>::M;
-  if (wave < Producer3<KS>::NP) {
-#define VC_W(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * M) : "memory")
-    if (younger < 4) {
-      if (younger < 2) { if (younger <= 0) VC_W(0); else VC_W(1); }
-      else             { if (younger == 2) VC_W(2); else VC_W(3); }
-    } else {
-      if (younger < 6) { if (younger == 4) VC_W(4); else VC_W(5); }
-      else             { if (younger == 6) VC_W(6); else VC_W(7); }
-    }
-#undef VC_W
-  }
-}
-
-template <int KS>
-__device__ __forceinline__ void stage_piece3(const uint8_t* __restrict__ tile_src, u32 slot_lds, int wave, int lane, int m) {
-  if (wave < Producer3<KS>::NP) {
-    const int kk = wave * Producer3<KS>::M + m;
-    glds16(tile_src + kk * kFragBytes + lane * 16, slot_lds + kk * kFragBytes);
-  }
-}
-
-// what the epilogue of one finished accumulator needs besides the accumulator itself
-struct Epi3 {
-  int thr;     // relevance: acc > thr  <=>  acc + ct > s_low   (0x7fffffff: nothing is relevant — no accumulator yet)
-  u32 ctj;     // (ct << 6) + (63 - column tile): row key = (acc << 6) + ctj
-};
-
-__device__ __forceinline__ void init_acc3(v16i& acc, const int* rterm_rt, int h) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const v4i cr = *(const v4i*)(rterm_rt + 8 * q + 4 * h);
-    acc[4 * q + 0] = cr[0]; acc[4 * q + 1] = cr[1]; acc[4 * q + 2] = cr[2]; acc[4 * q + 3] = cr[3];
-  }
-}
-
-// top-2 updates of rows r0..r1 of a finished accumulator (row tile PRT of its column tile)
-template <int PRT>
-__device__ __forceinline__ void update_rows3(const v16i& prev, u32 (&pbest)[16], u32 (&psec)[16], u32 ctj, u32& cb, u32& cs2,
-                                             int r0, int r1) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    if (r < r0 || r >= r1) continue;
-    const u32 rk = ((u32)prev[r] << 6) + ctj;
-    psec[r] = umed3(pbest[r], psec[r], rk);
-    pbest[r] = umax(pbest[r], rk);
-    const u32 ck = (rk & ~63u) | (u32)(63 - (PRT * 16 + r));
-    cs2 = umed3(cb, cs2, ck);
-    cb = umax(cb, ck);
-  }
-}
-
-// One row tile of one column tile: KS MFMAs into `cur` (started from the row term, C operand), the epilogue of `prev`
-// (the previous row tile's finished accumulator, row tile index PRT of its column tile) in their gaps, the B window
-// kept Window3<KS>::PD fragments ahead.  `prev`'s registers then become the NEXT row tile's accumulator: they are
-// re-initialised from `rterm_next` as soon as `prev` has been consumed.  RT = position of this row tile in the tile's stream.
-//
-// Register classes are pinned by writing the MFMA in asm: the A fragments of the whole pass live in the AGPR half of
-// the register file ("a"), accumulators and the B window in VGPRs, where the epilogue's VALU instructions read them.
-// (With the builtin the allocator spilled fragments to scratch inside the tile loop; a scratch reload waits for
-// vmcnt(0) and drains the LDS-DMA prefetch.)  The price: the compiler no longer knows these are MFMAs and pads no
-// read of their results, so the code is laid out such that it never needs to:
-//   * the 12 MFMAs of a row tile are straight-line code — no branch between them has `cur` live in two allocations,
-//     which would make the compiler copy a freshly written accumulator with VALU moves;
-//   * an accumulator is read by vector instructions only as `prev` and only from the THIRD step of the next row
-//     tile on, i.e. with two MFMAs (2 x 8 passes) issued in order behind its last one — the ISA asks for 11 wait
-//     states between an 8-pass MFMA and a VALU read of its result (one MFMA in between was measurably too few: matches
-//     went missing); the end-of-pass drain, which has no MFMAs to wait behind, pads with s_nop;
-//   * it is written before its first MFMA only by LDS loads, which the compiler does wait for.
-template <int KS, int RT, int PRT, typename Mid>
-__device__ __forceinline__ bool phase3(const v4i (&af)[KS], v16i& cur, v16i& prev, u32 (&pbest)[16], u32 (&psec)[16],
-                                       const Epi3& pe, u32& cb, u32& cs2, v4i (&bw)[Window3<KS>::PD], const uint8_t* src,
-                                       const uint8_t* src_next, const int* rterm_next, int h, Mid mid) {
-  constexpr int S0 = RT * KS;
-  constexpr int kPD3 = Window3<KS>::PD;
-  // steps [2, H): relevance test of `prev` (never steps 0 and 1: see above); steps [H, KS): the updates, if any
-  constexpr int H = KS / 2 >= 3 ? KS / 2 : 3;
-  static_assert(KS >= 4 && H <= KS, "at least four MFMAs per row tile (D > 64; shorter descriptors run on pair2_kernel)");
-  int m = 0;
-  bool relevant = false;
-#pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    const int s = S0 + k;
-#ifdef VC3_NOP
-    asm volatile("s_nop 7\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(cur) : "a"(af[k]), "v"(bw[s % kPD3]));
-#else
-    asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(cur) : "a"(af[k]), "v"(bw[s % kPD3]));
-#endif
-    {  // refill the window register just consumed with the fragment kPD3 positions ahead in the stream
-      const int n = s + kPD3;
-      const uint8_t* from = n < kRT3 * KS ? src + (n % KS) * kFragBytes : src_next + ((n - kRT3 * KS) % KS) * kFragBytes;
-      bw[s % kPD3] = *(const v4i*)from;
-    }
-    __builtin_amdgcn_sched_barrier(0);   // nothing below may move above this step's MFMA
-    if (k >= 2 && k < H) {
-      // relevance test of `prev`: 8 max-shaped operations spread over steps 2 .. H-1
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        if (2 + (o * (H - 2)) / 8 != k) continue;
-        if (o == 0) m = max(prev[0], max(prev[1], prev[2]));
-        else if (o < 7) m = max(m, max(prev[2 * o + 1], prev[2 * o + 2]));
-        else m = max(m, prev[15]);
-      }
-      if (k == H - 1) {
-        relevant = __any(m > pe.thr);
-#ifdef VC3_ALWAYS_RELEVANT
-        relevant = pe.thr != 0x7fffffff;
-#endif
-        if (!relevant) init_acc3(prev, rterm_next, h);   // consumed: the next row tile's C operand, latency hidden below
-      }
-    } else if (k >= H && relevant) {
-      update_rows3<PRT>(prev, pbest, psec, pe.ctj, cb, cs2, (16 * (k - H)) / (KS - H), (16 * (k - H + 1)) / (KS - H));
-    }
-    mid(k);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (relevant) {
-    if (KS == H) update_rows3<PRT>(prev, pbest, psec, pe.ctj, cb, cs2, 0, 16);   // no second half to carry them (D <= 64)
-    // keep the updates inside their branches (see epilogue_phase2)
-#pragma unroll
-    for (int r = 0; r < 16; r += 4)
-      asm volatile("" : "+v"(pbest[r]), "+v"(pbest[r + 1]), "+v"(pbest[r + 2]), "+v"(pbest[r + 3]),
-                        "+v"(psec[r]), "+v"(psec[r + 1]), "+v"(psec[r + 2]), "+v"(psec[r + 3]));
-    init_acc3(prev, rterm_next, h);
-  }
-  return relevant;
-}
-
-// the lane's column candidates of one column tile -> LDS (see epilogue_phase): order-independent merge
-__device__ __forceinline__ void flush_columns3(u32& cb, u32& cs2, unsigned long long* colbest, u32* colsecond, int jt, int c,
-                                               int h, u32 row_base) {
-  if (cb != 0) {
-    const int j = jt * kTile + c;
-    const u32 sb = cb >> 6;
-    const u32 code = 63u - (cb & 63u);                                   // PRT * 16 + r
-    const u32 grow = row_base + (code >> 4) * kTile + (code & 3u) + 8u * ((code >> 2) & 3u) + 4u * h;
-    const unsigned long long key = ((unsigned long long)sb << 32) | (unsigned long long)(0xFFFFFFFFu - grow);
-    const unsigned long long old = atomicMax(&colbest[j], key);
-    u32 cand = key > old ? (u32)(old >> 32) : sb;
-    cand = umax(cand, cs2 >> 6);
-    atomicMax(&colsecond[j], cand);
-  }
-  cb = 0;
-  cs2 = 0;
-}
-
-template <int KS>
-__global__ __launch_bounds__(kT3, 1) void pair3_kernel(
-    const uint8_t* __restrict__ prepared, const int32_t* __restrict__ counts, int n_tiles_img, int d,
-    const int32_t* __restrict__ pairs, int n_pairs, float max_ratio, float max_distance, int cross_check,
-    int n_max, int ns, int s_low, uint32_t* __restrict__ out_matches, int32_t* __restrict__ out_counts) {
-  constexpr int RT = kRT3;
-  constexpr int kPD3 = Window3<KS>::PD;
-  constexpr int kRowsPass = kW3 * RT * kTile;   // 512
-  static_assert((RT * KS) % kPD3 == 0, "the window registers are addressed statically: 4 KS must be a multiple of the window");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int n_pad = n_tiles_img * kTile;
-  uint8_t* ring = smem;
-  unsigned long long* colbest = (unsigned long long*)(smem + (size_t)ns * KS * kFragBytes);
-  u32* colsecond = (u32*)(colbest + n_pad);
-  int* cterm = (int*)(colsecond + n_pad);
-  int* m21 = cterm + n_pad;
-  int* rbest_s = m21 + n_pad;
-  int* rsecond_s = rbest_s + n_pad;
-  int* ridx_s = rsecond_s + n_pad;
-  int* crow = ridx_s + n_pad;                  // [wave][RT*32]: row terms 128*ra - 49024*D
-  int* wave_count = crow + kW3 * RT * kTile + kW3 * kRowScratchBytes / 4;
-  int* pair_flag = wave_count + 8;
-
-#ifdef VC_EXP_STAMP
-  unsigned long long st_wait = 0, st_tile = 0, st_init = 0, st_rowred = 0, st_final = 0;
-  const unsigned long long st_t0 = stamp();
-  unsigned long long st_tp = st_t0;
-#define VC_ST(acc_) { const unsigned long long t_ = stamp(); acc_ += t_ - st_tp; st_tp = t_; }
-#else
-#define VC_ST(acc_)
-#endif
-#ifdef VC_EXP_TRACE
-  // diagnostic build (with VC_EXP_STAMP, data without matches): per column tile and wave eight words
-  // {barrier arrival, release, MFMA begin, MFMA end, epilogue end, cut, -, -} into the workgroup's own (empty) match blocks
-  int trace_i = 0;
-#define VC_TR(k_, v_) { if ((threadIdx.x & 63) == 0 && trace_i >= 16 && trace_i < trace_n) trace[((size_t)trace_i * 8 + wave) * 8 + (k_)] = (uint32_t)(v_); }
-#else
-#define VC_TR(k_, v_)
-#endif
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
-  uint2* rscratch = (uint2*)(crow + kW3 * RT * kTile) + wave * kRowScratchEntries;
-  int* crow_wave = crow + wave * RT * kTile;
-  const size_t img_stride = image_bytes(n_tiles_img, KS);
-  const size_t frag_bytes_img = (size_t)n_tiles_img * KS * kFragBytes;
-  const u32 ring_lds = (u32)__builtin_amdgcn_readfirstlane((int)lds_addr(ring));
-
-  const int G = gridDim.x;
-  const int cid = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int lo = (int)(((long long)cid * n_pairs) / G);
-  const int hi = (int)(((long long)(cid + 1) * n_pairs) / G);
-
-  PairInfo cur = next_pair_with_work(lo, hi, pairs, counts, n_max, prepared, img_stride, kRowsPass);
-  if (tid == 0)
-    for (int q = lo; q < cur.p && q < hi; ++q) out_counts[q] = 0;
-  if (cur.p >= hi) return;
-  PairInfo nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride, kRowsPass);
-
-  // ---- producer (as pair2_kernel): the tile stream over (pair, pass, tile), one pair of look-ahead --------------
-  const uint8_t* p_src = cur.b_frags;
-  const uint8_t* p_base = cur.b_frags;
-  int p_left = cur.n_ct, p_nct = cur.n_ct, p_sweeps = cur.n_pass;
-  bool p_on_next = false, p_active = true;
-  int prod_seq = 0, prod_slot = 0, cons_seq = 0, cons_slot = 0;
-  auto produce_piece = [&](int m) {      // piece m of the next tile of the stream; the cursor moves with the last piece
-    if (p_active) {
-      stage_piece3<KS>(p_src, ring_lds + (u32)prod_slot * (KS * kFragBytes), wave, lane, m);
-      if (m == Producer3<KS>::M - 1) {
-        ++prod_seq;
-        if (++prod_slot == ns) prod_slot = 0;
-        p_src += KS * kFragBytes;
-        if (--p_left == 0) {
-          if (--p_sweeps > 0) {
-            p_src = p_base; p_left = p_nct;
-          } else if (!p_on_next && nxt.p < hi) {
-            p_on_next = true;
-            p_src = p_base = nxt.b_frags; p_left = p_nct = nxt.n_ct; p_sweeps = nxt.n_pass;
-          } else {
-            p_active = false;
-          }
-        }
-      }
-    }
-  };
-  for (int i = 0; i < ns - 1; ++i)
-#pragma unroll
-    for (int m = 0; m < Producer3<KS>::M; ++m) produce_piece(m);
-
-  // ---- the first tile of the stream: landed, visible, and its first fragments in the window ----------------------
-  wait_tile3<KS>(wave, prod_seq - 1);
-  wg_barrier();
-  v4i bw[kPD3];
-  {
-    const uint8_t* s0 = ring + lane * 16;
-#pragma unroll
-    for (int i = 0; i < kPD3; ++i) bw[i] = *(const v4i*)(s0 + (i % KS) * kFragBytes);
-  }
-  int rb_pref = tid < cur.n_ct * kTile ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[tid] : 0;
-  int rb_pref2 = tid + kT3 < cur.n_ct * kTile ? ((const int32_t*)(cur.b_frags + frag_bytes_img))[tid + kT3] : 0;
-
-  v4i afrag[RT][KS];
-  int cur_a = -1, cur_tile0 = -1;
-  v16i accA, accB;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { accA[r] = 0; accB[r] = 0; }
-
-  while (true) {
-    const int p = cur.p;
-    const int n1 = cur.n1, n2 = cur.n2, n_ct = cur.n_ct, n_pass = cur.n_pass;
-    const uint8_t* a_frags = prepared + (size_t)cur.a * img_stride;
-    const int32_t* a_rowsum = (const int32_t*)(a_frags + frag_bytes_img);
-    const int32_t* b_rowsum = (const int32_t*)(cur.b_frags + frag_bytes_img);
-
-    // ---- per-pair LDS state (the previous pair's finalisation ended with a barrier) ---------------------------
-    if (tid < n_ct * kTile) { cterm[tid] = 128 * rb_pref + 32640 * d; colbest[tid] = 0ull; colsecond[tid] = 0u; }
-    if (tid + kT3 < n_ct * kTile) { cterm[tid + kT3] = 128 * rb_pref2 + 32640 * d; colbest[tid + kT3] = 0ull; colsecond[tid + kT3] = 0u; }
-    for (int j = tid + 2 * kT3; j < n_ct * kTile; j += kT3) {
-      cterm[j] = 128 * b_rowsum[j] + 32640 * d;
-      colbest[j] = 0ull;
-      colsecond[j] = 0u;
-    }
-    for (int i = tid; i < n1; i += kT3) { rbest_s[i] = 0; rsecond_s[i] = 0; ridx_s[i] = -1; }
-    if (tid == 0) *pair_flag = 0;
-    bool pair_hit = false;
-
-    for (int pass = 0; pass < n_pass; ++pass) {
-      const int tile0 = (pass * kW3 + wave) * RT;   // first 32-row tile of a owned by this wave
-      if (cur.a != cur_a || tile0 != cur_tile0) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int kk = 0; kk < KS; ++kk)
-            afrag[rt][kk] = *(const v4i*)(a_frags + ((size_t)(tile0 + rt) * KS + kk) * kFragBytes + lane * 16);
-        crow_wave[lane] = 128 * a_rowsum[tile0 * kTile + lane] - 49024 * d;
-        crow_wave[lane + 64] = 128 * a_rowsum[tile0 * kTile + 64 + lane] - 49024 * d;
-        cur_a = cur.a;
-        cur_tile0 = tile0;
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see pair2_kernel
-      }
-      u32 rbest[RT][16], rsec[RT][16];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { rbest[rt][r] = 0; rsec[rt][r] = 0; }
-      const u32 row_base = (u32)(tile0 * kTile);
-      u32 cb = 0, cs2 = 0;
-      Epi3 epi_prev;
-      epi_prev.thr = 0x7fffffff;   // the first tile of a pass has no finished accumulator behind it
-      epi_prev.ctj = 0;
-      init_acc3(accA, crow_wave, h);
-      VC_ST(st_init)
-
-      for (int jt = 0; jt < n_ct; ++jt) {
-        // tile jt + 1 of the stream has landed (this wave's pieces) -> after the barrier it is readable by everyone,
-        // and the slot of tile jt - 1 is free for the producer
-        if (prod_seq - cons_seq - 2 >= 0) wait_tile3<KS>(wave, prod_seq - cons_seq - 2);
-        // The first barrier of a pass also publishes this wave's LDS writes (pair state, row terms): lgkmcnt(0).
-        // Later ones are bare: the only LDS traffic in flight is the B window's look-ahead (reads of a slot that
-        // is not refilled before the NEXT barrier) and the column merge's last atomic (read only after the
-        // finalisation's __syncthreads); draining them here would expose an LDS latency per tile.
-#ifdef VC3_FULL_BARRIER
-        wg_barrier();
-#else
-        if (jt == 0) wg_barrier(); else asm volatile("s_barrier" ::: "memory");
-#endif
-        const uint8_t* src = ring + (size_t)cons_slot * KS * kFragBytes + lane * 16;
-        if (++cons_slot == ns) cons_slot = 0;
-        const uint8_t* src_next = ring + (size_t)cons_slot * KS * kFragBytes + lane * 16;
-        ++cons_seq;
-        VC_ST(st_wait)
-        const int ct = cterm[jt * kTile + c];
-        Epi3 epi;
-        epi.thr = s_low - ct;
-        epi.ctj = ((u32)ct << 6) + (63u - (u32)jt);
-        auto no_mid = [](int) {};
-        auto dma_mid = [&](int k) { if (k < Producer3<KS>::M) produce_piece(k); };
-        // row tile 0  ||  epilogue of (jt - 1, row tile 3)
-        pair_hit |= phase3<KS, 0, 3>(afrag[0], accA, accB, rbest[3], rsec[3], epi_prev, cb, cs2, bw, src, src_next,
-                                     crow_wave + 1 * kTile, h, no_mid);
-        flush_columns3(cb, cs2, colbest, colsecond, jt - 1, c, h, row_base);   // (cb == 0 for jt = 0: nothing relevant yet)
-        // row tile 1  ||  epilogue of (jt, 0); this wave's LDS-DMA pieces of the refill go out here
-        pair_hit |= phase3<KS, 1, 0>(afrag[1], accB, accA, rbest[0], rsec[0], epi, cb, cs2, bw, src, src_next,
-                                     crow_wave + 2 * kTile, h, dma_mid);
-        pair_hit |= phase3<KS, 2, 1>(afrag[2], accA, accB, rbest[1], rsec[1], epi, cb, cs2, bw, src, src_next,
-                                     crow_wave + 3 * kTile, h, no_mid);
-        pair_hit |= phase3<KS, 3, 2>(afrag[3], accB, accA, rbest[2], rsec[2], epi, cb, cs2, bw, src, src_next,
-                                     crow_wave + 0 * kTile, h, no_mid);
-        epi_prev = epi;
-        VC_ST(st_tile)
-      }
-      {  // the last column tile's row tile 3 has no MFMAs to ride under (nor to wait behind: 2 x 16 wait states)
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        int m = accB[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) m = max(m, accB[r]);
-        if (__any(m > epi_prev.thr)) {
-          pair_hit = true;
-          update_rows3<3>(accB, rbest[3], rsec[3], epi_prev.ctj, cb, cs2, 0, 16);
-        }
-        flush_columns3(cb, cs2, colbest, colsecond, n_ct - 1, c, h, row_base);
-      }
-
-      // ---- row results of this pass (see pair_kernel) --------------------------------------------------------
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          u32 seen = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) seen |= rbest[rt][8 * half + j];
-          if (!__any(seen != 0)) continue;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int r = 8 * half + j;
-            rscratch[(j + 8 * h) * 33 + c] = make_uint2(rbest[rt][r], rsec[rt][r]);
-          }
-          const int rl = lane >> 2, qd = lane & 3;
-          u32 rb = 0, rs = 0, rc = 0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const uint2 en = rscratch[rl * 33 + qd * 8 + e];
-            const bool gt = en.x > rb;
-            rs = gt ? umax(rb, en.y) : umax(rs, en.x);
-            rc = gt ? (u32)(qd * 8 + e) : rc;
-            rb = umax(rb, en.x);
-          }
-#pragma unroll
-          for (int stp = 0; stp < 2; ++stp) {
-            u32 pb, ps, pc;
-            if (stp == 0) { pb = dpp_mov<0xB1>(rb); ps = dpp_mov<0xB1>(rs); pc = dpp_mov<0xB1>(rc); }
-            else          { pb = dpp_mov<0x4E>(rb); ps = dpp_mov<0x4E>(rs); pc = dpp_mov<0x4E>(rc); }
-            const bool gt = pb > rb;
-            rs = gt ? umax(rb, ps) : umax(rs, pb);
-            rc = gt ? pc : rc;
-            rb = umax(rb, pb);
-          }
-          const int jj = rl & 7, hh = rl >> 3;
-          const int lrow = (jj & 3) + 16 * half + 8 * (jj >> 2) + 4 * hh;
-          if (qd == 0) {
-            const int row = (tile0 + rt) * kTile + lrow;
-            if (row < n1) {
-              const int sb = (int)(rb >> 6);
-              rbest_s[row] = sb;
-              rsecond_s[row] = sb > 0 ? (int)(rs >> 6) : 0;
-              ridx_s[row] = sb > 0 ? (63 - (int)(rb & 63)) * kTile + (int)rc : -1;
-            }
-          }
-        }
-      }
-      VC_ST(st_rowred)
-    }  // passes
-
-    if (nxt.p < hi) {   // column sums of the next pair's image b (consumed by its LDS initialisation)
-      const int32_t* rs = (const int32_t*)(nxt.b_frags + frag_bytes_img);
-      if (tid < nxt.n_ct * kTile) rb_pref = rs[tid];
-      if (tid + kT3 < nxt.n_ct * kTile) rb_pref2 = rs[tid + kT3];
-    }
-    if (pair_hit && lane == 0) atomicOr(pair_flag, 1);
-    __syncthreads();
-    if (*pair_flag == 0) {
-      if (tid == 0) {
-        out_counts[p] = 0;
-        for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;
-      }
-    } else {
-      if (cross_check) {
-        for (int j = tid; j < n2; j += kT3) {
-          const unsigned long long kb = colbest[j];
-          const int row = (int)(0xFFFFFFFFu - (u32)kb);
-          m21[j] = accept_tab((int)(kb >> 32), (int)colsecond[j], max_ratio, max_distance, s_low) ? row : -1;
-        }
-        __syncthreads();
-      }
-      uint32_t* out = out_matches + (size_t)p * n_max * 2;
-      int base = 0;
-      for (int i0 = 0; i0 < n1; i0 += kT3) {
-        const int i = i0 + tid;
-        bool ok = false;
-        int j = -1;
-        if (i < n1) {
-          j = ridx_s[i];
-          ok = accept_tab(rbest_s[i], rsecond_s[i], max_ratio, max_distance, s_low);
-          if (ok && cross_check) ok = (m21[j] == i);
-        }
-        const unsigned long long mask = __ballot(ok);
-        if (lane == 0) wave_count[wave] = __popcll(mask);
-        __syncthreads();
-        int before = base, chunk_total = 0;
-#pragma unroll
-        for (int w = 0; w < kW3; ++w) {
-          const int wc = wave_count[w];
-          before += w < wave ? wc : 0;
-          chunk_total += wc;
-        }
-        if (ok) {
-          const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
-          out[2 * pos] = (uint32_t)i;
-          out[2 * pos + 1] = (uint32_t)j;
-        }
-        base += chunk_total;
-        __syncthreads();
-      }
-      if (tid == 0) {
-        out_counts[p] = base;
-        for (int q = p + 1; q < nxt.p && q < hi; ++q) out_counts[q] = 0;
-      }
-    }
-    __syncthreads();
-    VC_ST(st_final)
-
-    if (nxt.p >= hi) break;
-    cur = nxt;
-    nxt = next_pair_with_work(cur.p + 1, hi, pairs, counts, n_max, prepared, img_stride, kRowsPass);
-    if (p_on_next) p_on_next = false;
-    if (!p_active && nxt.p < hi) {
-      p_active = true; p_on_next = true;
-      p_src = p_base = nxt.b_frags; p_left = p_nct = nxt.n_ct; p_sweeps = nxt.n_pass;
-    }
-  }  // pairs
-#ifdef VC_EXP_STAMP
-  if (lane == 0) {
-    uint32_t* dbg = out_matches + ((size_t)lo * n_max + (n_max - 64)) * 2 + wave * 8;
-    dbg[0] = (uint32_t)st_wait; dbg[1] = (uint32_t)st_tile; dbg[2] = 0; dbg[3] = (uint32_t)st_init;
-    dbg[4] = (uint32_t)st_rowred; dbg[5] = (uint32_t)st_final; dbg[6] = (uint32_t)(stamp() - st_t0); dbg[7] = (uint32_t)(hi - lo);
-  }
-#endif
-#undef VC_ST
-#undef VC_TR
-}
-
-#endif  // VC_PAIR3_EXPERIMENT
 
 // ---------------------------------------------------------------------------------------
 // small kernels
@@ -2400,34 +1692,6 @@ int launch_pair2(const void* prepared, const int32_t* counts, int n_tiles, int d
   return vc::check_launch();
 }
 
-#ifdef VC_PAIR3_EXPERIMENT
-template <int KS>
-int launch_pair3(const void* prepared, const int32_t* counts, int n_tiles, int d, const int32_t* pairs,
-                 int n_pairs, float max_ratio, float max_distance, int cross_check, int n_max,
-                 uint32_t* out_matches, int32_t* out_counts, hipStream_t stream) {
-  const int s_low = relevance_threshold(max_ratio, max_distance);
-  const int n_pad = n_tiles * kTile;
-  const int ns = plan_slots3(KS, n_pad);
-  if (ns == 0) return VC_ERR_UNSUPPORTED;
-  const size_t smem = (size_t)ns * KS * kFragBytes + lds_fixed_bytes3(n_pad);
-  static vc::PerDeviceOnce configured;
-  if (int st = configured.run([] {
-        return hipFuncSetAttribute((const void*)pair3_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-      }))
-    return st;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    cus = 256;
-  const int grid = n_pairs < cus ? n_pairs : cus;
-  hipLaunchKernelGGL((pair3_kernel<KS>), dim3(grid), dim3(kT3), smem, stream, (const uint8_t*)prepared, counts,
-                     n_tiles, d, pairs, n_pairs, max_ratio, max_distance, cross_check, n_max, ns, s_low, out_matches,
-                     out_counts);
-  return vc::check_launch();
-}
-
-#endif  // VC_PAIR3_EXPERIMENT
-
 // RT = 2 (512 rows per pass) while its register budget holds (A fragments: 2*KS*4 VGPRs);
 // long descriptors fall back to one row tile per wave.
 template <bool FUSED>
@@ -2484,21 +1748,12 @@ int vc_match_pairs_u8(const void* prepared, const int32_t* counts, int n_images,
 #if VC_WAVES == 8 && !defined(VC_OLD_PAIR_KERNEL)
   int st2 = VC_ERR_UNSUPPORTED;
   switch (pick_ks(d)) {   // descriptors up to 384 bytes: the persistent kernel (two row tiles per wave)
-#ifdef VC_PAIR3_EXPERIMENT
-#define VC_LAUNCH_PERSISTENT launch_pair3
-#else
-#define VC_LAUNCH_PERSISTENT launch_pair2
-#endif
-#define VC_CASE2(K)                                                                                          \
-  case K:                                                                                                    \
-    st2 = VC_LAUNCH_PERSISTENT<K>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio,          \
-                                  max_distance, cross_check, n_max, out_matches, out_counts, (hipStream_t)stream); \
+#define VC_CASE2(K)                                                                                      \
+  case K:                                                                                                \
+    st2 = launch_pair2<K>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio, max_distance, \
+                          cross_check, n_max, out_matches, out_counts, (hipStream_t)stream);             \
     break;
-    case 2:   // two MFMAs per row tile leave no room for the in-wave pipeline of pair3_kernel
-      st2 = launch_pair2<2>(prepared, counts, tiles_of(n_max), d, pairs, n_pairs, max_ratio, max_distance, cross_check, n_max,
-                            out_matches, out_counts, (hipStream_t)stream);
-      break;
-    VC_CASE2(4) VC_CASE2(8) VC_CASE2(12)
+    VC_CASE2(2) VC_CASE2(4) VC_CASE2(8) VC_CASE2(12)
 #undef VC_CASE2
     default: break;
   }

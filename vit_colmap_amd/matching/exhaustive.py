@@ -77,6 +77,9 @@ def hip_match_blocks(block, counts, pairs, max_ratio=0.8, max_distance=0.7, cros
         chunk = torch.from_numpy(pairs[s:s + pair_chunk]).to(device)
         m, c = match_pairs(prepared, d_counts, n, n_max, D, chunk, max_ratio, max_distance, cross_check)
         c_np = c.cpu().numpy()
+        if (c_np < 0).any():   # VC_COUNT_SELFCHECK_FAILED: the kernel's cursor check (include/vitcolmap_hip.h) — never a result
+            bad = np.nonzero(c_np < 0)[0][:8] + s
+            raise _lib.HipLibraryError(f"vc_match_pairs_u8: consistency check failed for pairs {bad.tolist()}")
         m_np = m.cpu().numpy().view(np.uint32)
         out.extend(m_np[p, : c_np[p]].copy() for p in range(len(c_np)))
     return out

@@ -291,6 +291,60 @@ class DinoV2(nn.Module):
         ) for b in self.blocks]
         return self
 
+    # -- batch shards on HIP streams ------------------------------------------------------------------
+    # Every kernel of a block is a persistent grid of one workgroup per CU (or two): 599 row tiles of the fused MLP run as
+    # 3 rounds for 2.34 rounds of work, 1800 attention units as 4 for 3.5 — a fifth of the MLP's and an eighth of the
+    # attention's time is a tail in which most CUs idle.  Images are independent through the whole block stack, so the
+    # batch is cut into `batch_shards` contiguous shards whose block loops are enqueued layer by layer on separate HIP
+    # streams: one shard's tail overlaps the other's next kernel (measured on 50 x 1531 x 384: 7.12 -> 6.66 ms with two
+    # equal shards, 6.9 with three; tools/bench_vit_streams.py).  Per-row arithmetic is unchanged; what can differ from
+    # the single-stream run is which rows share a 32-row tile, hence which tiles take the float GELU path of the fused
+    # MLP instead of the table (both are within the bf16 tolerance asserted in tests/test_vit_gpu.py).
+    batch_shards = None   # None: VITCOLMAP_VIT_SHARDS or 2; 1 switches the streams off
+
+    def _shard_plan(self, x):
+        import os
+
+        k = self.batch_shards if self.batch_shards is not None else int(os.environ.get("VITCOLMAP_VIT_SHARDS", "2"))
+        B = x.shape[0]
+        if k <= 1 or B < 8 * k:
+            return None
+        bounds = [B * i // k for i in range(k + 1)]
+        key = (x.device, k)
+        if getattr(self, "_shard_streams", None) is None or self._shard_streams[0] != key:
+            self._shard_streams = (key, [torch.cuda.Stream(device=x.device) for _ in range(k - 1)])
+        return bounds, self._shard_streams[1]
+
+    def _run_sharded(self, x, layer_fn, final_fn, out):
+        """layer_fn(i_layer, x_shard) updates a shard in place; final_fn(x_shard, out_shard) writes the normalised rows."""
+        plan = self._shard_plan(x)
+        if plan is None:
+            for i in range(len(self.blocks)):
+                layer_fn(i, x)
+            final_fn(x, out)
+            return out
+        bounds, side = plan
+        cur = torch.cuda.current_stream(x.device)
+        streams = [cur] + side
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for s in side:
+            s.wait_event(ready)
+        xs = [x[bounds[i]:bounds[i + 1]] for i in range(len(streams))]
+        outs = [out[bounds[i]:bounds[i + 1]] for i in range(len(streams))]
+        for li in range(len(self.blocks)):
+            for s, xi in zip(streams, xs):
+                with torch.cuda.stream(s):
+                    layer_fn(li, xi)
+        for s, xi, oi in zip(streams, xs, outs):
+            with torch.cuda.stream(s):
+                final_fn(xi, oi)
+        for s in side:   # join: everything the side streams touched is complete before the caller's stream goes on
+            done = torch.cuda.Event()
+            done.record(s)
+            cur.wait_event(done)
+        return out
+
     def _blocks_hip(self, x, drop_cls: bool = True):
         """ViT-S bf16 path on the hand-written GEMMs: LayerNorm lives in the x load of qkv / fc1, GELU and
         both residual adds in GEMM epilogues; per block 4 kernels (the MLP is one) and no standalone elementwise pass.
@@ -299,19 +353,36 @@ class DinoV2(nn.Module):
 
         if self._hip and self._hip[0].get("kind") == "gemm":
             return self._blocks_gemm(x, drop_cls)
-        for blk, hw in zip(self.blocks, self._hip):
-            a = ops.attention(hw["qkv"](x), blk.attn.num_heads, q_prescaled=True)   # LN1 + qkv (q pre-scaled), flash attention
-            hw["proj"](a, ops.EPI_RESIDUAL, residual=x, out=x)            # x += proj(a)
+        blocks, hip = list(self.blocks), self._hip
+
+        def layer(i, xi):
+            blk, hw = blocks[i], hip[i]
+            a = ops.attention(hw["qkv"](xi), blk.attn.num_heads, q_prescaled=True)   # LN1 + qkv (q pre-scaled), flash attention
+            hw["proj"](a, ops.EPI_RESIDUAL, residual=xi, out=xi)            # x += proj(a)
             if hw["mlp"] is not None:
-                hw["mlp"](x)                                              # x += fc2(gelu(fc1(LN2 x))), one kernel
-                continue
-            hdn = hw["fc1"](x, ops.EPI_GELU, gelu_table=self._gelu_tab)   # gelu(fc1(LN2 x)), GELU by LDS table
+                hw["mlp"](xi)                                               # x += fc2(gelu(fc1(LN2 x))), one kernel
+                return
+            hdn = hw["fc1"](xi, ops.EPI_GELU, gelu_table=self._gelu_tab)    # gelu(fc1(LN2 x)), GELU by LDS table
             fc2 = blk.mlp.fc2
-            ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=x, out=x)   # x += fc2(hdn)
+            ops.linear(hdn, fc2.weight, fc2.bias, ops.EPI_RESIDUAL, residual=xi, out=xi)   # x += fc2(hdn)
+
+        return self._run_sharded(x, layer, *self._final_norm(x, drop_cls))
+
+    def _final_norm(self, x, drop_cls):
+        """-> (final_fn, out): the last LayerNorm as a per-shard step writing into a batch slice of `out`."""
+        from . import hip_ops as ops
+
+        B, N, C = x.shape
         if drop_cls:   # final norm of the patch tokens only: the class-token row is dropped here, the caller gets a dense tensor
-            return ops.layernorm_drop_first(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
-        return h
+            out = torch.empty((B, N - 1, C), dtype=torch.bfloat16, device=x.device)
+            return (lambda xi, oi: ops.layernorm_drop_first(xi, self.norm.weight, self.norm.bias, self.norm.eps, out=oi)), out
+        out = torch.empty_like(x)
+
+        def all_rows(xi, oi):
+            _, h = ops.add_layernorm(xi, None, self.norm.weight, self.norm.bias, self.norm.eps)
+            oi.copy_(h)
+
+        return all_rows, out
 
     def _blocks_gemm(self, x, drop_cls: bool = True):
         """ViT-B / ViT-L bf16 path: LayerNorm kernel + staged MFMA GEMMs with fused epilogues (bias; exact GELU; bias +
@@ -319,17 +390,18 @@ class DinoV2(nn.Module):
         them a library call.  x (B, 1 + T, C) -> normalised patch tokens (B, T, C), or all rows with drop_cls=False."""
         from . import hip_ops as ops
 
-        for blk, hw in zip(self.blocks, self._hip):
-            _, h = ops.add_layernorm(x, None, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        blocks, hip = list(self.blocks), self._hip
+
+        def layer(i, xi):
+            blk, hw = blocks[i], hip[i]
+            _, h = ops.add_layernorm(xi, None, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
             a = ops.attention(ops.linear(h, *hw["qkv"]), blk.attn.num_heads, q_prescaled=True)
-            ops.linear(a, *hw["proj"], ops.EPI_RESIDUAL, residual=x, out=x)          # x += proj(a)
-            _, h = ops.add_layernorm(x, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            ops.linear(a, *hw["proj"], ops.EPI_RESIDUAL, residual=xi, out=xi)          # x += proj(a)
+            _, h = ops.add_layernorm(xi, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             hdn = ops.linear(h, *hw["fc1"], ops.EPI_GELU)
-            ops.linear(hdn, *hw["fc2"], ops.EPI_RESIDUAL, residual=x, out=x)        # x += fc2(gelu(fc1(LN2 x)))
-        if drop_cls:
-            return ops.layernorm_drop_first(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        _, h = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
-        return h
+            ops.linear(hdn, *hw["fc2"], ops.EPI_RESIDUAL, residual=xi, out=xi)        # x += fc2(gelu(fc1(LN2 x)))
+
+        return self._run_sharded(x, layer, *self._final_norm(x, drop_cls))
 
     def _blocks_fused(self, x):
         """bf16 GPU path: every residual add is fused with the LayerNorm that follows it

@@ -20,12 +20,13 @@ def add_layernorm(x: torch.Tensor, residual, weight: torch.Tensor, bias: torch.T
     return s, y
 
 
-def layernorm_drop_first(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+def layernorm_drop_first(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out=None) -> torch.Tensor:
     """x (B, N, C) bf16 -> LayerNorm of rows 1.. of every image as a dense (B, N - 1, C) tensor (the class-token row is
-    neither normalised nor copied)."""
+    neither normalised nor copied).  `out`: a contiguous (B, N - 1, C) bf16 destination (e.g. a batch slice)."""
     assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 3
     B, N, C = x.shape
-    y = torch.empty((B, N - 1, C), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((B, N - 1, C), dtype=torch.bfloat16, device=x.device) if out is None else out
+    assert y.shape == (B, N - 1, C) and y.dtype == torch.bfloat16 and y.is_contiguous()
     _lib.check(_lib.load().vc_layernorm_drop_first_bf16(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), eps, B, N, C, _lib.ptr(y),
                                                         _lib.stream_ptr()), "vc_layernorm_drop_first_bf16")
     return y
