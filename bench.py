@@ -9,11 +9,20 @@ process is one rank and WORLD_SIZE must equal --gpus; without one, the process s
 the GPU, and exits with that job's code.  A run that cannot have N ranks fails loudly (exit 2).
 
 One step = one pass of the hot path over one batch of synthetic input that is already resident
-in HBM (BASELINE.json configs[1] + configs[2] at N = 1):
-    per rank 50 synthetic 640x480 BGR frames -> HIP preprocess -> DINOv2 ViT-S/14 (bf16, random
+in HBM:
+    per rank its block of the synthetic 640x480 BGR frames -> HIP preprocess -> DINOv2 ViT-S/14 (bf16, random
     weights: no checkpoint offline) -> HIP keypoint selection (512 targets) + 384-D uint8
     descriptors -> [N > 1: all-gather of the descriptor blocks] -> HIP exhaustive matcher over this
-    rank's share of all pairs among the 50*N images.
+    rank's share (pair p -> rank p % N) of all pairs among the images.
+Which images:
+    --gpus 1 (default)      50 images: BASELINE.json configs[1] + configs[2], the configuration the metric is quoted on;
+                            the line also carries `strong_scaling_200`, the same GPU on the 200-image set below, so that
+                            a scaling run has its N = 1 anchor
+    --gpus N > 1 (default)  STRONG scaling on the fixed 200-image set of north_star / configs[3] (--images-total 200):
+                            images in contiguous blocks of ceil(200 / N), all 19 900 pairs dealt p % N
+    --weak                  50 images per GPU (50 N images, all pairs among them): the round-1/2 experiment
+    --config c5             configs[4]'s single-GPU share: ViT-B/14, 2048 keypoints, PCA -> 256-D, 63 images
+                            (ceil(500 / 8)) and 2048 x 256 matcher blocks; the roofline is stated against int8 MFMA
 `value` = images/s of that whole step (all ranks).  Nothing is copied to the host inside the timed
 region; SQLite writes are host work outside the accelerated path and are not timed here.
 
@@ -46,9 +55,16 @@ NUM_KEYPOINTS, DESC_DIM = 512, 384
 VIT_FLOP_PER_IMAGE = 1.09e11          # ViT-S/14 at 1531 tokens
 MATCH_BYTES_PER_PAIR = 2 * NUM_KEYPOINTS * DESC_DIM + 2 * NUM_KEYPOINTS * 12   # 405 504 B
 MATCH_OPS_PER_PAIR = 2.0 * NUM_KEYPOINTS * NUM_KEYPOINTS * DESC_DIM
+# configs[4] (C5): ViT-B/14, 2048 keypoints, PCA -> 256-D, 500 images on 8 GPUs -> 63 per GPU
+C5 = dict(model="dinov2_vitb14", num_keypoints=2048, desc_dim=256, images=63, flop_per_image=3.48e11,
+          bytes_per_pair=2 * 2048 * 256 + 2 * 2048 * 12, ops_per_pair=2.0 * 2048 * 2048 * 256)   # 1 097 728 B
+C2 = dict(model="dinov2_vits14", num_keypoints=NUM_KEYPOINTS, desc_dim=DESC_DIM, images=IMAGES_PER_RANK,
+          flop_per_image=VIT_FLOP_PER_IMAGE, bytes_per_pair=MATCH_BYTES_PER_PAIR, ops_per_pair=MATCH_OPS_PER_PAIR)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16
-TRAFFIC_PROFILE = "profiles/r02_matcher_traffic.json"   # rocprofv3 --pmc pass of this command (tools/prof_pmc.sh)
+MFMA_INT8_PEAK_TOPS = 5000.0          # dense int8 = 2x bf16 per clock (MI355X_MICROARCH.md, Matrix cores)
+TRAFFIC_PROFILE = "profiles/r03_matcher_traffic.json"   # rocprofv3 --pmc passes of this command (tools/prof_r03.sh)
+STRONG_IMAGES = 200                   # north_star / configs[3]: the fixed set of the scaling experiment
 
 
 def parse_args():
@@ -59,6 +75,12 @@ def parse_args():
     ap.add_argument("--match-launches", type=int, default=0,
                     help="launches of the matcher micro-loops (default: enough for ~0.5 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images-total", type=int, default=0,
+                    help="images of the whole job (strong scaling); default 50 at --gpus 1, 200 at --gpus N > 1")
+    ap.add_argument("--weak", action="store_true", help="50 images per GPU instead of a fixed set")
+    ap.add_argument("--config", choices=["c2", "c5"], default="c2",
+                    help="c2: configs[1]+[2] (ViT-S, 512 x 384); c5: configs[4]'s one-GPU share (ViT-B, 2048 x 256)")
+    ap.add_argument("--no-strong-anchor", action="store_true", help="skip the 200-image leg of the default N = 1 line")
     return ap.parse_args()
 
 
@@ -104,12 +126,12 @@ def synthetic_frames(rank, n):
     return out
 
 
-def c3_descriptor_blocks(n_images):
+def c3_descriptor_blocks(n_images, n_rows=NUM_KEYPOINTS, d=DESC_DIM):
     """Matcher micro-bench input of SURVEY.md §8d / BASELINE.md §3 (tests/util_data.py: numpy only)."""
     import numpy as np
     from util_data import synthetic_descriptors
 
-    return np.stack([synthetic_descriptors(k, NUM_KEYPOINTS, DESC_DIM) for k in range(n_images)])
+    return np.stack([synthetic_descriptors(k, n_rows, d) for k in range(n_images)])
 
 
 def host_cores():
@@ -162,6 +184,25 @@ def cpu_baseline(frames):
     }
 
 
+def plan_job(config: str, world: int, images_total: int = 0, weak: bool = False):
+    """-> (images of the whole job, "strong" | "weak").  Default: configs[1] (50 images) on one GPU, the fixed 200-image
+    set of north_star / configs[3] on N > 1 GPUs (strong scaling); --weak: the per-GPU count times N; c5: 63 per GPU."""
+    per_gpu = (C5 if config == "c5" else C2)["images"]
+    if weak and images_total:
+        raise ValueError("--weak and --images-total exclude each other")
+    if weak:
+        n_total, scaling = per_gpu * world, "weak"
+    elif images_total:
+        n_total, scaling = images_total, "strong"
+    elif world > 1:
+        n_total, scaling = (STRONG_IMAGES, "strong") if config == "c2" else (per_gpu * world, "weak")
+    else:
+        n_total, scaling = per_gpu, "strong"            # one GPU: the set is what it is
+    if n_total < 2 * world:
+        raise ValueError(f"{n_total} images on {world} rank(s): fewer than two images per rank")
+    return n_total, scaling
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -179,6 +220,12 @@ def main():
             if rank == 0:
                 print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
             sys.exit(2)
+    cfg = C5 if args.config == "c5" else C2
+    try:
+        n_total, scaling = plan_job(args.config, world, args.images_total, args.weak)
+    except ValueError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -196,40 +243,10 @@ def main():
     from vit_colmap_amd.features.vit_extractor import ViTExtractor
     from vit_colmap_amd.matching import match_pairs, prepare_descriptors
 
+    K, D = cfg["num_keypoints"], cfg["desc_dim"]
     quiet = open(os.devnull, "w")
     so, sys.stdout = sys.stdout, quiet                       # the extractor prints like the reference does
-    ex = ViTExtractor(model_name="dinov2_vits14", num_keypoints=NUM_KEYPOINTS, descriptor_dim=DESC_DIM,
-                      device=str(dev), precision="bf16", seed=0)
-    sys.stdout = so
-
-    frames_np = synthetic_frames(rank, IMAGES_PER_RANK)
-    frames = torch.from_numpy(frames_np).to(dev)             # resident in HBM before the timed region
-    n_global = IMAGES_PER_RANK * world
-    my_pairs = torch.from_numpy(vd.pairs_for_rank(n_global, rank, world)).to(dev)
-    n_pairs_global = n_global * (n_global - 1) // 2
-    out_m = torch.empty((my_pairs.shape[0], NUM_KEYPOINTS, 2), dtype=torch.int32, device=dev)
-    out_c = torch.empty((my_pairs.shape[0],), dtype=torch.int32, device=dev)
-    leg_ms = {"extract": 0.0, "gather": 0.0, "match": 0.0}
-    step_events = []                                         # four events per timed step, read after the timed region
-
-    def step(timed):
-        # No host synchronisation inside a step: the K steps are enqueued back to back (the GPU never waits for Python to
-        # launch the next step's first kernels) and the timed region is closed by barrier() below.
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
-        if timed:
-            ev[0].record()
-        res = ex.extract_device(frames)                      # preprocess + ViT + selection + descriptors
-        if timed:
-            ev[1].record()
-        desc, counts = vd.all_gather_descriptors(res["desc_u8"], res["count"])
-        if timed:
-            ev[2].record()
-        prepared = prepare_descriptors(desc, counts)
-        match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
-        if timed:
-            ev[3].record()
-            step_events.append(ev)
-        return res
+    ex = ViTExtractor(model_name=cfg["model"], num_keypoints=K, descriptor_dim=D, device=str(dev), precision="bf16", seed=0)
 
     def barrier():
         if world > 1:
@@ -243,99 +260,203 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    for _ in range(args.warmup):
-        res = step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(True)
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    for ev in step_events:
-        leg_ms["extract"] += ev[0].elapsed_time(ev[1])
-        leg_ms["gather"] += ev[1].elapsed_time(ev[2])
-        leg_ms["match"] += ev[2].elapsed_time(ev[3])
+    def run_job(n_images, steps, warmup):
+        """The hot path over a fixed set of n_images synthetic frames sharded over the ranks (contiguous blocks of
+        ceil(n / world), the last ranks padded with empty images; pair p of the exhaustive list -> rank p % world).
+        -> (elapsed seconds of `steps` steps, max over ranks; per-leg ms of rank 0; last result; pairs of the job)."""
+        per = (n_images + world - 1) // world
+        lo, hi = vd.shard_range(n_images, rank, world)
+        frames_np = synthetic_frames(0, n_images)[lo:hi] if hi > lo else np.zeros((0, H, W, 3), np.uint8)
+        frames = torch.from_numpy(frames_np).to(dev)         # resident in HBM before the timed region
+        n_slots = per * world                                # image slots after padding (slots >= n_images are empty)
+        my_pairs = torch.from_numpy(vd.pairs_for_rank(n_images, rank, world)).to(dev)
+        out_m = torch.empty((my_pairs.shape[0], K, 2), dtype=torch.int32, device=dev)
+        out_c = torch.empty((my_pairs.shape[0],), dtype=torch.int32, device=dev)
+        pad_d = torch.zeros((per - (hi - lo), K, D), dtype=torch.uint8, device=dev)
+        pad_c = torch.zeros((per - (hi - lo),), dtype=torch.int32, device=dev)
+        events = []
 
-    # ---- matcher leg at the BASELINE shape (configs[2]): 50 blocks of 512 x 384 per GPU, all pairs, this rank's share ----
-    def matcher_loop(blocks_np):
+        def step(timed):
+            # No host synchronisation inside a step: the steps are enqueued back to back (the GPU never waits for Python
+            # to launch the next step's first kernels) and the timed region is closed by barrier() below.
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+            if timed:
+                ev[0].record()
+            res = ex.extract_device(frames)                  # preprocess + ViT + selection + descriptors
+            if timed:
+                ev[1].record()
+            d_loc, c_loc = res["desc_u8"], res["count"]
+            if pad_c.numel():
+                d_loc, c_loc = torch.cat([d_loc, pad_d]), torch.cat([c_loc, pad_c])
+            desc, counts = vd.all_gather_descriptors(d_loc, c_loc)
+            if timed:
+                ev[2].record()
+            prepared = prepare_descriptors(desc, counts)
+            match_pairs(prepared, counts, n_slots, K, D, my_pairs, out_matches=out_m, out_counts=out_c)
+            if timed:
+                ev[3].record()
+                events.append(ev)
+            return res
+
+        res = None
+        for _ in range(warmup):
+            res = step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step(True)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        legs = {"extract": 0.0, "gather": 0.0, "match": 0.0}
+        for ev in events:
+            legs["extract"] += ev[0].elapsed_time(ev[1])
+            legs["gather"] += ev[1].elapsed_time(ev[2])
+            legs["match"] += ev[2].elapsed_time(ev[3])
+        return elapsed, legs, res, frames_np, hi - lo, n_images * (n_images - 1) // 2
+
+    elapsed, leg_ms, res, frames_np, n_local, n_pairs_global = run_job(n_total, args.steps, args.warmup)
+    sys.stdout = so
+
+    # ---- matcher leg at the fixed block shape (configs[2]: 512 x 384; c5: 2048 x 256): all pairs among n_total blocks --
+    def matcher_loop(blocks_np, n_blocks, rows, dim):
         blocks = torch.from_numpy(blocks_np).to(dev)
-        counts = torch.full((n_global,), NUM_KEYPOINTS, dtype=torch.int32, device=dev)
-        P = my_pairs.shape[0]
+        counts = torch.full((n_blocks,), rows, dtype=torch.int32, device=dev)
+        pairs = torch.from_numpy(vd.pairs_for_rank(n_blocks, rank, world)).to(dev)
+        P = pairs.shape[0]
+        om = torch.empty((P, rows, 2), dtype=torch.int32, device=dev)
+        oc = torch.empty((P,), dtype=torch.int32, device=dev)
         prepared = prepare_descriptors(blocks, counts)
         for _ in range(3):
-            match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
+            match_pairs(prepared, counts, n_blocks, rows, dim, pairs, out_matches=om, out_counts=oc)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                                          # HIP events on the stream the kernel is launched on
-        match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
+        match_pairs(prepared, counts, n_blocks, rows, dim, pairs, out_matches=om, out_counts=oc)
         e1.record()
         torch.cuda.synchronize()
         n = args.match_launches or max(20, min(20000, int(500.0 / max(e0.elapsed_time(e1), 1e-3))))   # ~0.5 s
         barrier()
         e0.record()
         for _ in range(n):
-            match_pairs(prepared, counts, n_global, NUM_KEYPOINTS, DESC_DIM, my_pairs, out_matches=out_m, out_counts=out_c)
+            match_pairs(prepared, counts, n_blocks, rows, dim, pairs, out_matches=om, out_counts=oc)
         e1.record()
         torch.cuda.synchronize()
         launch_ms = e0.elapsed_time(e1) / n                  # this rank's kernel: P pairs per launch
         slowest_ms = max_over_ranks(launch_ms)
-        return P, n, launch_ms, slowest_ms, int(out_c.sum().item())
+        assert int((oc < 0).sum().item()) == 0, "matcher self-check failed (VC_COUNT_SELFCHECK_FAILED)"
+        return P, n, launch_ms, slowest_ms, int(oc.sum().item())
 
-    P, n_launch, launch_ms, slowest_ms, _ = matcher_loop(c3_descriptor_blocks(n_global))
+    n_blocks = n_total
+    P, n_launch, launch_ms, slowest_ms, _ = matcher_loop(c3_descriptor_blocks(n_blocks, K, D), n_blocks, K, D)
     pair_rate = n_pairs_global / slowest_ms * 1e3            # whole job: all ranks' pairs / slowest rank's launch
-    dense_np, _ = image_set(1, n_global, NUM_KEYPOINTS, DESC_DIM, kind="scene")
-    Pd, n_launch_d, launch_ms_d, slowest_ms_d, dense_matches = matcher_loop(dense_np)
+    dense_np, _ = image_set(1, n_blocks, K, D, kind="scene")
+    Pd, n_launch_d, launch_ms_d, slowest_ms_d, dense_matches = matcher_loop(dense_np, n_blocks, K, D)
     pair_rate_dense = n_pairs_global / slowest_ms_d * 1e3
+    c5_shape = None
+    if args.config == "c2" and world == 1:
+        # the configs[4] block shape (2048 x 256) on this GPU: 24 blocks, all 276 pairs, sparse and dense input
+        r5, d5, nb5 = C5["num_keypoints"], C5["desc_dim"], 24
+        P5, _, ms5, _, _ = matcher_loop(c3_descriptor_blocks(nb5, r5, d5), nb5, r5, d5)
+        d5_np, _ = image_set(5, nb5, r5, d5, kind="scene")
+        _, _, ms5d, _, _ = matcher_loop(d5_np, nb5, r5, d5)
+        c5_shape = {
+            "blocks": [nb5, r5, d5], "pairs_per_launch": P5, "bytes_per_pair": C5["bytes_per_pair"],
+            "pair_matches_per_s": round(P5 / ms5 * 1e3, 1), "pair_matches_per_s_dense": round(P5 / ms5d * 1e3, 1),
+            "hbm_contract_frac": round(P5 * C5["bytes_per_pair"] / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "int8_tops_nominal": round(P5 * C5["ops_per_pair"] / (ms5 * 1e-3) / 1e12, 1),
+            "int8_tops_nominal_dense": round(P5 * C5["ops_per_pair"] / (ms5d * 1e-3) / 1e12, 1),
+            "int8_mfma_frac_dense": round(P5 * C5["ops_per_pair"] / (ms5d * 1e-3) / 1e12 / MFMA_INT8_PEAK_TOPS, 4),
+            "note": "at 2048 x 256 the HBM contract (1 097 728 B per pair) would need 10.9 Pop/s of int8 at 70 %: the honest "
+                    "bound is the int8 matrix pipe (dense peak 5 Pop/s); on dense data every MAC is executed, so "
+                    "int8_mfma_frac_dense is a real pipe fraction; on the sparse input two thirds of the MFMAs are skipped",
+        }
+
+    # ---- the N = 1 anchor of the strong-scaling experiment: the 200-image set on this one GPU ---------------------------
+    strong_anchor = None
+    if world == 1 and args.config == "c2" and n_total != STRONG_IMAGES and not args.no_strong_anchor:
+        sys.stdout = quiet
+        st = max(4, args.steps // 10)
+        el2, legs2, _, _, _, np2 = run_job(STRONG_IMAGES, st, 2)
+        sys.stdout = so
+        strong_anchor = {
+            "images_total": STRONG_IMAGES, "pairs_per_step": np2, "steps": st, "value": round(STRONG_IMAGES * st / el2, 2),
+            "unit": "images/s", "ms_per_step": round(el2 / st * 1e3, 3),
+            "legs_ms_per_step_rank0": {k: round(v / st, 3) for k, v in legs2.items()},
+            "note": "what `bench.py --gpus 1 --images-total 200` reports as its value: the N = 1 point of the default "
+                    "--gpus N > 1 runs (strong scaling on the fixed 200-image set)",
+        }
 
     if rank == 0:
-        achieved = P * MATCH_BYTES_PER_PAIR / (launch_ms * 1e-3) / 1e9          # rank 0's launch, rank 0's GPU
-        achieved_d = Pd * MATCH_BYTES_PER_PAIR / (launch_ms_d * 1e-3) / 1e9
-        traffic = traffic_src = None
+        bpp, opp = cfg["bytes_per_pair"], cfg["ops_per_pair"]
+        achieved = P * bpp / (launch_ms * 1e-3) / 1e9          # rank 0's launch, rank 0's GPU
+        achieved_d = Pd * bpp / (launch_ms_d * 1e-3) / 1e9
+        traffic = traffic_src = executed = None
         tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
-        if world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        if world == 1 and args.config == "c2" and n_total == IMAGES_PER_RANK and os.path.exists(tpath):
+            prof = json.load(open(tpath))
+            traffic = prof.get("hbm_bytes_per_launch")
+            executed = prof.get("mfma", {}).get("executed_fraction_of_nominal")
             traffic_src = f"{TRAFFIC_PROFILE}: PMC passes of this command, not a measurement of this run"
+        nominal_tops = P * opp / (launch_ms * 1e-3) / 1e12
         roof = {
-            "kernel": "pair2_kernel<12> (persistent; fused int8-MFMA similarity + row/column top-2 + ratio/cross-check)",
+            "kernel": f"pair2_kernel<{(D + 31) // 32}> (persistent; fused int8-MFMA similarity + row/column top-2 + ratio/cross-check)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": round(launch_ms, 4), "launches_timed": n_launch, "pairs_per_launch": P,
-            "bytes_per_pair": MATCH_BYTES_PER_PAIR,
-            "int8_tops": round(P * MATCH_OPS_PER_PAIR / (launch_ms * 1e-3) / 1e12, 1),
+            "bytes_per_pair": bpp,
+            "regime": "CONTRACT rate on NON-MATCHING data (the SURVEY §8d input: no tile holds a relevant similarity, the exact "
+                      "early-out skips two thirds of every tile's MFMAs and every epilogue): algorithmic bytes per pair x pairs / "
+                      "time, not an HBM or MFMA efficiency — see roofline_dense for data where every tile matters",
+            "int8_tops_nominal": round(nominal_tops, 1),
+            "mfma_executed_fraction": executed,
+            "int8_tops_executed": None if executed is None else round(nominal_tops * executed, 1),
+            "mfma_executed_source": None if executed is None else traffic_src,
         }
+        dense_tops = Pd * opp / (launch_ms_d * 1e-3) / 1e12
         roof_dense = {
             "kernel": roof["kernel"], "bound": "hbm", "achieved": round(achieved_d, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_d / HBM_PEAK_GBS, 4), "traffic": None,
             "launch_ms": round(launch_ms_d, 4), "launches_timed": n_launch_d, "pairs_per_launch": Pd,
-            "bytes_per_pair": MATCH_BYTES_PER_PAIR,
-            "int8_tops": round(Pd * MATCH_OPS_PER_PAIR / (launch_ms_d * 1e-3) / 1e12, 1),
+            "bytes_per_pair": bpp,
+            "int8_tops": round(dense_tops, 1), "int8_mfma_frac": round(dense_tops / MFMA_INT8_PEAK_TOPS, 4),
             "matches_per_launch": dense_matches,
             "input": "tests/util_data.image_set(kind='scene'): every image a noisy subset of one descriptor pool, so "
-                     "every 32x32 similarity tile holds relevant entries (the update path runs everywhere)",
+                     "every 32x32 similarity tile holds relevant entries (the update path runs everywhere; every MAC executes)",
         }
-        images = n_global * args.steps
+        images = n_total * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         extract_ms = leg_ms["extract"] / args.steps
-        vit_tflops = VIT_FLOP_PER_IMAGE * IMAGES_PER_RANK / (extract_ms * 1e-3) / 1e12
+        vit_tflops = cfg["flop_per_image"] * n_local / (extract_ms * 1e-3) / 1e12
+        if args.config == "c5":
+            workload = (f"configs[4], one GPU's share: DINOv2 ViT-B/14 extract of {n_total} 640x480 images ({K} keypoint targets, "
+                        f"768 -> {D}-D projected uint8 descriptors) then exhaustive matching of all pairs among them; "
+                        f"matcher legs on {K} x {D} blocks")
+        elif n_total == IMAGES_PER_RANK and world == 1:
+            workload = ("configs[1]+configs[2]: DINOv2 ViT-S/14 extract of 50 640x480 images (512 keypoints, 384-D uint8 "
+                        "descriptors) then exhaustive mutual-NN + ratio matching of all pairs among the extracted images")
+        else:
+            workload = (f"configs[3]: the fixed {n_total}-image 640x480 set, DINOv2 ViT-S/14 extract sharded in contiguous blocks "
+                        f"over {world} GPU(s), one RCCL all-gather of the descriptor blocks, all {n_pairs_global} pairs dealt "
+                        f"p % {world}") if scaling == "strong" else \
+                       (f"weak scaling: {cfg['images']} images per GPU ({n_total} images), all {n_pairs_global} pairs dealt p % {world}")
         line = {
             "metric": "images/sec extracted + pair-matches/sec (N×D brute-force NN)",
             "value": round(images / elapsed, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (ViT) / u8+i32 (matcher)",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16 (ViT) / u8+i32 (matcher)",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]+configs[2]: DINOv2 ViT-S/14 extract of 50 640x480 images per GPU "
-                            "(512 keypoints, 384-D uint8 descriptors) then exhaustive mutual-NN + ratio matching of "
-                            "all pairs among the extracted images",
-                "images_per_gpu": IMAGES_PER_RANK, "image_size": [W, H], "num_keypoints": NUM_KEYPOINTS,
-                "descriptor_dim": DESC_DIM, "pairs_per_step": n_pairs_global, "parallelism": f"images+pairs sharded x{world}",
+                "workload": workload,
+                "images_total": n_total, "images_rank0": n_local, "image_size": [W, H], "num_keypoints": K,
+                "descriptor_dim": D, "pairs_per_step": n_pairs_global, "parallelism": f"images+pairs sharded x{world}",
                 "keypoints_kept_per_image_mean": round(float(res["count"].float().mean().item()), 1),
+                "vit_batch_shards": getattr(ex.model, "batch_shards", None) or int(os.environ.get("VITCOLMAP_VIT_SHARDS", "2")),
             },
             "timed_region_s": round(elapsed, 3),
-            "extract_images_per_s": round(IMAGES_PER_RANK * world / (extract_ms * 1e-3), 1),
+            "extract_images_per_s": round(n_local * world / (extract_ms * 1e-3), 1),
             "pair_matches_per_s": round(pair_rate, 1),
             "pair_matches_per_s_dense": round(pair_rate_dense, 1),
-            "pair_matches_config": f"configs[2] per GPU: {n_global} blocks of 512x384 uint8, all {n_pairs_global} pairs dealt "
+            "pair_matches_config": f"{n_blocks} blocks of {K}x{D} uint8, all {n_pairs_global} pairs dealt "
                                    f"round-robin to {world} rank(s), one launch per rank, slowest rank's time",
             "legs_ms_per_step_rank0": {k: round(v / args.steps, 3) for k, v in leg_ms.items()},
             "roofline": roof,
@@ -345,8 +466,10 @@ def main():
                 "frac": round(vit_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                 "note": "whole extract leg (preprocess + ViT + selection) against the ViT's FLOPs: a lower bound on the GEMM rate",
             },
+            "matcher_c5_shape": c5_shape,
+            "strong_scaling_200": strong_anchor,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline(frames_np)
         else:
             line["cpu_baseline"] = None

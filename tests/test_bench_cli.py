@@ -37,3 +37,30 @@ def test_gpu_leg_of_bench_does_not_import_the_oracle():
     body, _, rest = tail.partition("\ndef ")
     assert "oracle" not in head.split('"""', 2)[2] and "from oracle" not in rest and "import oracle" not in rest
     assert "from oracle" in body
+
+
+def test_default_workloads_strong_scaling_on_the_200_image_set():
+    """--gpus N > 1 measures north_star's experiment (the fixed 200-image set, strong scaling); one GPU
+    keeps configs[1] (50 images); --weak keeps the old 50-per-GPU experiment; c5 is one GPU's share of configs[4]."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.plan_job("c2", 1) == (50, "strong")
+    for n in (2, 4, 8):
+        assert bench.plan_job("c2", n) == (200, "strong")
+        assert bench.plan_job("c2", n, weak=True) == (50 * n, "weak")
+    assert bench.plan_job("c2", 1, images_total=200) == (200, "strong")      # the N = 1 anchor of the scaling curve
+    assert bench.plan_job("c5", 1) == (63, "strong") and bench.plan_job("c5", 8) == (504, "weak")
+    import pytest
+
+    with pytest.raises(ValueError):
+        bench.plan_job("c2", 2, images_total=100, weak=True)
+    with pytest.raises(ValueError):
+        bench.plan_job("c2", 8, images_total=10)
+
+
+def test_contradicting_flags_are_refused_before_any_gpu_call():
+    r = _run(["--gpus", "1", "--weak", "--images-total", "100"])
+    assert r.returncode == 2 and "exclude" in r.stderr and not r.stdout.strip()
+    r = _run(["--gpus", "1", "--images-total", "1"])
+    assert r.returncode == 2 and not r.stdout.strip()

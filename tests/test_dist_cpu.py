@@ -99,6 +99,21 @@ def _oracle_match_fn(block, counts, pairs, max_ratio, max_distance, cross_check)
     return [mo.match_pair(block[a, : counts[a]], block[b, : counts[b]], max_ratio, max_distance, cross_check) for a, b in pairs]
 
 
+def _stand_in_verify_fn(kps, pair_images, pair_ids, lists):
+    """Host stand-in for the HIP hypothesis scoring (same contract as matching.two_view.verify_pairs): a deterministic
+    pseudo-verification whose inlier subsets, configurations and matrices depend on the pair id and the keypoints, so
+    the sharded path carries non-trivial payloads through gather_pair_results and the writer."""
+    out = []
+    for (a, b), pid, m in zip(pair_images, pair_ids, lists):
+        m = np.asarray(m, np.uint32).reshape(-1, 2)
+        keep = ((m[:, 0].astype(np.int64) + m[:, 1] + int(pid)) % 3) != 0
+        ok = int(keep.sum()) >= 4
+        F = np.arange(9, dtype=np.float64).reshape(3, 3) * (1 + int(pid) % 7) + float(kps[a][:1, :2].sum())
+        out.append(dict(config=(3 if int(pid) % 2 else 6) if ok else 1, inlier_matches=m[keep] if ok else m[:0],
+                        F=F if ok else np.zeros((3, 3)), H=F.T if ok else np.zeros((3, 3)), n_f=int(keep.sum()), n_h=0))
+    return out
+
+
 def _dump_db(path):
     from vit_colmap_amd.database import ColmapDatabase
 
@@ -112,6 +127,12 @@ def _dump_db(path):
             for j, _ in imgs:
                 if i < j:
                     out[("m", i, j)] = h.read_matches(i, j)
+                    g = h.read_two_view_geometry(i, j)
+                    if g is not None:
+                        out[("tvg", i, j)] = np.concatenate([np.asarray(g["inlier_matches"], np.float64).reshape(-1),
+                                                             [float(g["config"])], np.asarray(g["F"]).reshape(-1),
+                                                             np.asarray(g["H"]).reshape(-1)])
+        out["verified"] = h.num_verified_image_pairs()
     return out
 
 
@@ -132,7 +153,7 @@ def _make_feature_db(path, desc, counts):
     for k in range(len(counts)):
         i = db.add_image(f"im{k:02d}.png", cam)
         if counts[k]:
-            db.add_keypoints(i, np.zeros((counts[k], 2), np.float32))
+            db.add_keypoints(i, np.random.RandomState(k).rand(counts[k], 2).astype(np.float32) * 400)
             db.add_descriptors(i, desc[k, : counts[k]])
     db.db.close()
 
@@ -150,14 +171,21 @@ def _product_worker(rank, world, port, tmp, q):
         tmp = Path(tmp)
         # (1) database in, database out: rank 0 reads and writes, both ranks match their share
         stats = match_exhaustive(database_path=str(tmp / "dist.db"), distributed=True, match_fn=_oracle_match_fn,
-                                 device="cpu", verify=False)
-        ok = stats["ranks"] == 2 and stats["pairs"] == 21
+                                 device="cpu", verify=True, verify_fn=_stand_in_verify_fn)
+        ok = stats["ranks"] == 2 and stats["pairs"] == 21 and stats["verified_pairs"] > 3 and stats["matches"] > 50
         # (2) directory in, database out: image shards, one descriptor all-gather, pair shards, rank-0 writer
         dummy = DummyExtractor(step=32)
         st = run_sharded(tmp / "images", tmp / "sharded.db", "PINHOLE",
                          feature_fn=lambda imgs: [dummy.features_for(*im.shape[:2]) for im in imgs],
-                         match_fn=_oracle_match_fn, verify=False, device="cpu", batch_size=2)
-        ok = ok and st["images"] == 5 and st["pairs"] == 10 and st["ranks"] == 2
+                         match_fn=_oracle_match_fn, verify=True, verify_fn=_stand_in_verify_fn, device="cpu", batch_size=2)
+        ok = ok and st["images"] == 5 and st["pairs"] == 10 and st["ranks"] == 2          # (rank 0's totals on every rank)
+        # (3) an error on rank 0 (the only database process) reaches every rank instead of leaving rank 1 in a collective
+        try:
+            match_exhaustive(database_path=str(tmp / "no_such_dir" / "x.db"), distributed=True, match_fn=_oracle_match_fn,
+                             device="cpu", verify=False)
+            ok = False
+        except Exception as e:  # noqa: BLE001
+            ok = ok and (rank == 0 or "rank 0 failed" in str(e))
         q.put(bool(ok))
     finally:
         dist.destroy_process_group()
@@ -179,10 +207,12 @@ def test_two_rank_product_entries_write_the_single_process_database(tmp_path):
     (tmp_path / "images" / "img_9_broken.png").write_bytes(b"not an image")          # unreadable: no row, no features
 
     # single-process references (same stand-in matcher)
-    s = match_exhaustive(database_path=str(tmp_path / "single.db"), match_fn=_oracle_match_fn, device="cpu", verify=False)
-    assert s["pairs"] == 21 and s["matches"] > 50 and s["ranks"] == 1
+    s = match_exhaustive(database_path=str(tmp_path / "single.db"), match_fn=_oracle_match_fn, device="cpu", verify=True,
+                         verify_fn=_stand_in_verify_fn)
+    assert s["pairs"] == 21 and s["matches"] > 50 and s["ranks"] == 1 and s["verified_pairs"] > 3
     DummyExtractor(step=32).extract(tmp_path / "images", tmp_path / "single_pipe.db", "PINHOLE")
-    match_exhaustive(database_path=str(tmp_path / "single_pipe.db"), match_fn=_oracle_match_fn, device="cpu", verify=False)
+    match_exhaustive(database_path=str(tmp_path / "single_pipe.db"), match_fn=_oracle_match_fn, device="cpu", verify=True,
+                     verify_fn=_stand_in_verify_fn)
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -195,5 +225,7 @@ def test_two_rank_product_entries_write_the_single_process_database(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(results)
-    _same_db(_dump_db(tmp_path / "single.db"), _dump_db(tmp_path / "dist.db"))
+    single, sharded = _dump_db(tmp_path / "single.db"), _dump_db(tmp_path / "dist.db")
+    _same_db(single, sharded)                      # matches AND two_view_geometries rows: each rank verified its own pairs
+    assert single["verified"] == sharded["verified"] > 3 and any(k[0] == "tvg" for k in single if isinstance(k, tuple))
     _same_db(_dump_db(tmp_path / "single_pipe.db"), _dump_db(tmp_path / "sharded.db"))

@@ -243,3 +243,26 @@ def test_metrics_extractor_reads_back_what_the_writer_stored(tmp_path):
     assert m.config_distribution == {"CALIBRATED": 1, "UNCALIBRATED": 1}
     out = mx.export_json(tmp_path / "r" / "metrics.json", min_threshold=4)
     assert json.loads((tmp_path / "r" / "metrics.json").read_text()) == out and out["features"]["total_keypoints"] == 28
+
+
+def test_two_view_geometry_of_a_swapped_pair_is_converted(tmp_path):
+    """a geometry handed over as (larger id, smaller id) is stored for smaller -> larger — columns reversed,
+    F / E transposed, H inverted, the relative pose inverted — and read back in whichever direction is asked for."""
+    from vit_colmap_amd.database.colmap_db import SqliteColmapDatabase, _quat_to_rot
+
+    db = SqliteColmapDatabase(str(tmp_path / "t.db"))
+    rs = np.random.RandomState(0)
+    H, F, E = rs.standard_normal((3, 3)), rs.standard_normal((3, 3)), rs.standard_normal((3, 3))
+    q = rs.standard_normal(4)
+    q /= np.linalg.norm(q)
+    t = rs.standard_normal(3)
+    m = np.array([[1, 2], [3, 4], [7, 0]], np.uint32)
+    db.write_two_view_geometry(5, 3, m, 3, F=F, E=E, H=H, qvec=q, tvec=t)
+    fwd, back = db.read_two_view_geometry(3, 5), db.read_two_view_geometry(5, 3)
+    assert np.array_equal(fwd["inlier_matches"], m[:, ::-1]) and np.array_equal(back["inlier_matches"], m)
+    assert np.allclose(fwd["F"], F.T) and np.allclose(fwd["E"], E.T) and np.allclose(fwd["H"], np.linalg.inv(H))
+    assert np.allclose(back["F"], F) and np.allclose(back["H"], H) and np.allclose(back["qvec"], q) and np.allclose(back["tvec"], t)
+    x = rs.standard_normal(3)                                   # a point through 5 -> 3 and back through the stored 3 -> 5
+    y = _quat_to_rot(q) @ x + t
+    assert np.allclose(_quat_to_rot(fwd["qvec"]) @ y + fwd["tvec"], x)
+    db.close()

@@ -2,9 +2,11 @@
 """Developer tool: split the pair-kernel dispatches of a `rocprofv3 --kernel-trace` run of bench.py into the three
 contexts bench.py launches it in (inside the timed steps / the configs[2] loop / the dense loop) and print the per-context
 average duration — the configs[2] loop is the launch `roofline.launch_ms` times with HIP events.
-usage: tools/prof_bench_contexts.py <kernel_trace.csv> <steps+warmup> """
+usage: tools/prof_bench_contexts.py <kernel_trace.csv> <steps+warmup> [kernel name substring] """
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "pair2_kernel" in r["Kernel_Name"] or "pair_kernel" in r["Kernel_Name"]]
+sub = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. "pair2_kernel<12>": leaves the 2048 x 256 legs (pair2_kernel<8>) out
+rows = [r for r in csv.DictReader(open(sys.argv[1]))
+        if (sub in r["Kernel_Name"] if sub else ("pair2_kernel" in r["Kernel_Name"] or "pair_kernel" in r["Kernel_Name"]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 n_step = int(sys.argv[2])

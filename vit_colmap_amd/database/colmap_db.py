@@ -82,6 +82,34 @@ def pair_id_to_image_ids(pair_id: int):
     return (pair_id - image_id2) // MAX_IMAGE_ID, image_id2
 
 
+def _quat_to_rot(q):
+    w, x, y, z = np.asarray(q, np.float64) / max(np.linalg.norm(q), 1e-300)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _swap_two_view(m, F, E, H, qvec, tvec):
+    """Two-view geometry of the pair (1 -> 2) expressed for (2 -> 1): x2^T F x1 = 0 <=> x1^T F^T x2 = 0 (same for E);
+    x2 ~ H x1 <=> x1 ~ H^-1 x2 (a singular or all-zero H stays as it is: nothing to invert);
+    X2 = R X1 + t <=> X1 = R^T X2 - R^T t, i.e. the conjugate quaternion and -R^T t."""
+    m = np.asarray(m).reshape(-1, 2)[:, ::-1]
+    F = None if F is None else np.asarray(F, np.float64).reshape(3, 3).T
+    E = None if E is None else np.asarray(E, np.float64).reshape(3, 3).T
+    if H is not None:
+        H = np.asarray(H, np.float64).reshape(3, 3)
+        if abs(np.linalg.det(H)) > 1e-300:
+            H = np.linalg.inv(H)
+    if qvec is not None:
+        q = np.asarray(qvec, np.float64).reshape(4)
+        t = np.zeros(3) if tvec is None else np.asarray(tvec, np.float64).reshape(3)
+        tvec = -_quat_to_rot(q).T @ t
+        qvec = q * np.array([1.0, -1.0, -1.0, -1.0])
+    elif tvec is not None:
+        tvec = -np.asarray(tvec, np.float64).reshape(3)
+    return m, F, E, H, qvec, tvec
+
+
 @dataclass
 class Camera:
     """Stand-in for pycolmap.Camera(model=, width=, height=, params=) (vit_extractor.py:722-724)."""
@@ -178,22 +206,22 @@ class SqliteColmapDatabase:
         """One row per verified pair [recalled COLMAP layout]: inlier matches uint32 (rows, 2) relative to the smaller
         image id, `config` (TwoViewGeometry::ConfigurationType: 1 DEGENERATE, 2 CALIBRATED, 3 UNCALIBRATED, 4 PLANAR,
         5 PANORAMIC, 6 PLANAR_OR_PANORAMIC ... — the codes reference utils/metrics.py:131-141 names), and the
-        matrices as float64 blobs (F, E, H row-major 3x3; qvec 4, tvec 3).  A swapped pair transposes F / E and inverts
-        nothing else: the build always writes id1 < id2."""
+        matrices as float64 blobs (F, E, H row-major 3x3; qvec 4 as (w, x, y, z), tvec 3).  Geometry is stored for the
+        direction smaller id -> larger id; a call with image_id1 > image_id2 is converted (`_swap_two_view`): match
+        columns reversed, F and E transposed, H inverted, the relative pose inverted."""
         m = np.asarray(inlier_matches, dtype=np.uint32).reshape(-1, 2)
-        swap = image_id1 > image_id2
-        if swap:
-            m = m[:, ::-1]
+        if image_id1 > image_id2:
+            m, F, E, H, qvec, tvec = _swap_two_view(m, F, E, H, qvec, tvec)
         m = np.ascontiguousarray(m)
 
-        def blob(a, shape, transpose=False):
+        def blob(a, shape):
             a = np.zeros(shape) if a is None else np.asarray(a, np.float64).reshape(shape)
-            return np.ascontiguousarray(a.T if transpose else a).tobytes()
+            return np.ascontiguousarray(a).tobytes()
 
         self._conn.execute(
             "INSERT OR REPLACE INTO two_view_geometries VALUES (?, ?, ?, ?, ?, ?, ?, ?, ?, ?)",
             (pair_id_of(image_id1, image_id2), m.shape[0], 2, m.tobytes() if m.shape[0] else None, int(config),
-             blob(F, (3, 3), swap), blob(E, (3, 3), swap), blob(H, (3, 3)), blob(qvec if qvec is not None else [1, 0, 0, 0], (4,)),
+             blob(F, (3, 3)), blob(E, (3, 3)), blob(H, (3, 3)), blob(qvec if qvec is not None else [1, 0, 0, 0], (4,)),
              blob(tvec, (3,))))
         if commit:
             self._conn.commit()
@@ -266,18 +294,20 @@ class SqliteColmapDatabase:
         return self._count("SELECT COALESCE(SUM(rows), 0) FROM two_view_geometries")
 
     def read_two_view_geometry(self, image_id1: int, image_id2: int):
-        """-> dict(inlier_matches uint32 (rows, 2), config, F, E, H) or None."""
-        row = self._conn.execute("SELECT rows, cols, data, config, F, E, H FROM two_view_geometries WHERE pair_id = ?",
+        """-> dict(inlier_matches uint32 (rows, 2), config, F, E, H, qvec, tvec) or None, in the direction
+        image_id1 -> image_id2 (converted from the stored smaller -> larger direction when the ids are swapped)."""
+        row = self._conn.execute("SELECT rows, cols, data, config, F, E, H, qvec, tvec FROM two_view_geometries WHERE pair_id = ?",
                                  (pair_id_of(image_id1, image_id2),)).fetchone()
         if row is None:
             return None
-        rows, cols, data, config, F, E, H = row
+        rows, cols, data, config, F, E, H, qvec, tvec = row
         m = np.zeros((0, 2), np.uint32) if rows == 0 or data is None else np.frombuffer(data, np.uint32).reshape(rows, cols).copy()
-        mats = [np.frombuffer(x, np.float64).reshape(3, 3).copy() if x is not None else np.zeros((3, 3)) for x in (F, E, H)]
+        F, E, H = [np.frombuffer(x, np.float64).reshape(3, 3).copy() if x is not None else np.zeros((3, 3)) for x in (F, E, H)]
+        qvec = np.frombuffer(qvec, np.float64).copy() if qvec is not None else np.array([1.0, 0, 0, 0])
+        tvec = np.frombuffer(tvec, np.float64).copy() if tvec is not None else np.zeros(3)
         if image_id1 > image_id2:
-            m = np.ascontiguousarray(m[:, ::-1])
-            mats[0], mats[1] = mats[0].T, mats[1].T
-        return dict(inlier_matches=m, config=int(config), F=mats[0], E=mats[1], H=mats[2])
+            m, F, E, H, qvec, tvec = _swap_two_view(m, F, E, H, qvec, tvec)
+        return dict(inlier_matches=np.ascontiguousarray(m), config=int(config), F=F, E=E, H=H, qvec=qvec, tvec=tvec)
 
     def read_matches(self, image_id1: int, image_id2: int):
         m = self._read_blob("matches", "pair_id", pair_id_of(image_id1, image_id2), np.uint32)

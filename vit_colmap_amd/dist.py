@@ -120,6 +120,48 @@ def gather_pair_lists(pairs: np.ndarray, lists, dst: int = 0):
     return merged
 
 
+def gather_pair_results(pairs: np.ndarray, results, dst: int = 0):
+    """Variable-size gather of one picklable result per pair (two-view geometries: inlier lists + matrices; small) to
+    `dst`.  Returns on dst a dict {(a, b): result} over all ranks' pairs, elsewhere None."""
+    if not is_distributed():
+        return {(int(a), int(b)): r for (a, b), r in zip(pairs, results)}
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object((np.asarray(pairs), list(results)), out, dst=dst)
+    if out is None:
+        return None
+    merged = {}
+    for prs, rs in out:
+        for (a, b), r in zip(prs, rs):
+            merged[(int(a), int(b))] = r
+    return merged
+
+
+def raise_if_any_failed(local_error=None, what: str = ""):
+    """Collective error hand-shake: every rank calls it at the same point with its own exception (or None).  If any rank
+    failed, EVERY rank raises — the failing one its own exception, the others a RuntimeError naming the rank — instead of
+    the healthy ranks waiting in the next collective until the process-group timeout (e.g. rank 0, the only SQLite
+    writer, hitting an IntegrityError while the others sit in a broadcast)."""
+    if not is_distributed():
+        if local_error is not None:
+            raise local_error
+        return
+    flag = torch.tensor([0 if local_error is None else 1 + dist.get_rank()], dtype=torch.int64, device=comm_device())
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if local_error is not None:
+        raise local_error
+    if int(flag.item()):
+        raise RuntimeError(f"rank {int(flag.item()) - 1} failed{(' in ' + what) if what else ''}; this rank stops with it")
+
+
+def broadcast_object(obj, src: int = 0):
+    """Small picklable object on `src` -> every rank."""
+    if not is_distributed():
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def gather_match_lists(pairs: np.ndarray, counts: np.ndarray, matches: np.ndarray, dst: int = 0):
     """Padded-array form of gather_pair_lists: returns on dst a list of (pairs, counts, matches) per rank."""
     if not is_distributed():

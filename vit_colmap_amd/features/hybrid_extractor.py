@@ -121,28 +121,31 @@ class HybridViTExtractor(BaseExtractor):
         if not image_files:
             raise ValueError(f"No images found in {image_dir}")
         db = ColmapDatabase(str(db_path))
-        first = image_io.imread(image_files[0])
-        if first is None:
-            raise ValueError(f"Failed to read first image: {image_files[0]}")
-        height, width = first.shape[:2]
-        if camera_params is None:
-            camera_params = default_camera_params(camera_model, width, height)
-        cam = db.db.write_camera(Camera(model=camera_model, width=width, height=height, params=camera_params))
-        for idx, f in enumerate(image_files):
-            img = first if idx == 0 else image_io.imread(f)
-            if img is None:
-                print(f"{f.name}: ⚠ failed to read image, skipping")
-                continue
-            image_id = db.add_image(f.name, camera_id=cam)
-            try:
-                kp, desc = self._run_inference(img)
-            except _lib.HipLibraryError:
-                raise
-            except Exception as e:  # noqa: BLE001 - one bad image never aborts the run
-                print(f"  ✗ Error during feature extraction of {f.name}: {e}")
-                continue
-            if len(kp) == 0:
-                continue
-            db.add_keypoints(image_id, kp)
-            db.add_descriptors(image_id, desc)
-        db.commit()
+        try:
+            first = image_io.imread(image_files[0])
+            if first is None:
+                raise ValueError(f"Failed to read first image: {image_files[0]}")
+            height, width = first.shape[:2]
+            if camera_params is None:
+                camera_params = default_camera_params(camera_model, width, height)
+            cam = db.db.write_camera(Camera(model=camera_model, width=width, height=height, params=camera_params))
+            for idx, f in enumerate(image_files):
+                img = first if idx == 0 else image_io.imread(f)
+                if img is None:
+                    print(f"{f.name}: ⚠ failed to read image, skipping")
+                    continue
+                image_id = db.add_image(f.name, camera_id=cam)
+                try:
+                    kp, desc = self._run_inference(img)
+                except _lib.HipLibraryError:
+                    raise
+                except Exception as e:  # noqa: BLE001 - one bad image never aborts the run
+                    print(f"  ✗ Error during feature extraction of {f.name}: {e}")
+                    continue
+                if len(kp) == 0:
+                    continue
+                db.add_keypoints(image_id, kp)
+                db.add_descriptors(image_id, desc)
+            db.commit()
+        finally:
+            db.db.close()

@@ -85,11 +85,29 @@ def hip_match_blocks(block, counts, pairs, max_ratio=0.8, max_distance=0.7, cros
     return out
 
 
+def _pack_keypoints(kps: dict, n: int):
+    """{index: (N, >= 2)} -> float32 (n, max N, 2) zero padded + int32 counts: the form that travels between ranks."""
+    cnt = np.array([len(kps[k]) for k in range(n)], np.int32)
+    out = np.zeros((n, max(int(cnt.max()) if n else 0, 1), 2), np.float32)
+    for k in range(n):
+        out[k, : cnt[k]] = kps[k][:, :2]
+    return out, cnt
+
+
+def _unpack_keypoints(arr, cnt):
+    return {k: arr[k, : cnt[k]] for k in range(len(cnt))}
+
+
 def match_exhaustive(database_path: str, matching_options=None, sift_options=None, device="cuda",
-                     pair_chunk: int = 16384, distributed=None, match_fn=None, verify: bool = True) -> dict:
+                     pair_chunk: int = 16384, distributed=None, match_fn=None, verify: bool = True, verify_fn=None) -> dict:
     """Returns a small stats dict (pairs, matches, seconds); the result proper is in the database.
-    `match_fn(block, counts, pairs, max_ratio, max_distance, cross_check) -> list of match lists` replaces the HIP
-    matcher (the CPU tests of the multi-rank path pass the oracle; the product never does)."""
+    Multi-rank (`distributed`): rank 0 — the only process that touches the SQLite file — reads descriptors and keypoints
+    and broadcasts them; EVERY rank matches and geometrically verifies its share of the pair list (pair p -> rank
+    p % world); match lists and two-view geometries are gathered to rank 0, which writes them in pair order.  An error
+    on any rank (e.g. rank 0's database) is raised on all of them (dist.raise_if_any_failed).
+    `match_fn(block, counts, pairs, max_ratio, max_distance, cross_check) -> list of match lists` and
+    `verify_fn(keypoints, pair_images, pair_ids, lists) -> list of results` replace the HIP matcher / scorer (the CPU
+    tests of the multi-rank path pass the oracles; the product never does)."""
     sift = _sift_options(matching_options, sift_options)
     max_ratio, max_distance, cross_check = float(sift.max_ratio), float(sift.max_distance), bool(sift.cross_check)
     if distributed is None:
@@ -104,46 +122,79 @@ def match_exhaustive(database_path: str, matching_options=None, sift_options=Non
         def match_fn(block, counts, pairs, r, dmax, cc):
             return hip_match_blocks(block, counts, pairs, r, dmax, cc, device=device, pair_chunk=pair_chunk)
 
+    from .two_view import read_keypoints_by_index, verify_pair_lists, write_two_view_rows
+
     t0 = time.perf_counter()
-    db = SqliteColmapDatabase(str(database_path)) if rank == 0 else None      # rank 0 is the only reader and writer
+    db = None
     try:
-        if rank == 0:
-            ids, block, counts, D = load_descriptor_blocks(db)
-        else:
-            ids = block = counts = D = None
+        ids = block = counts = D = kp_arr = kp_cnt = None
+        err = None
+        if rank == 0:                                                          # rank 0 is the only reader and writer
+            try:
+                db = SqliteColmapDatabase(str(database_path))
+                ids, block, counts, D = load_descriptor_blocks(db)
+                if verify and D != 0:
+                    kp_arr, kp_cnt = _pack_keypoints(read_keypoints_by_index(db, ids), len(ids))
+            except Exception as e:  # noqa: BLE001 - handed to every rank below
+                err = e
         if distributed:
-            meta = [(ids, D)]
-            torch.distributed.broadcast_object_list(meta, src=0)
-            ids, D = meta[0]
+            vd.raise_if_any_failed(err, "reading the database")
+            ids, D = vd.broadcast_object((ids, D), 0)
             block = vd.broadcast_array(block, 0, device)
             counts = vd.broadcast_array(counts, 0, device)
+            if verify and D != 0:
+                kp_arr = vd.broadcast_array(kp_arr, 0, device)
+                kp_cnt = vd.broadcast_array(kp_cnt, 0, device)
+        elif err is not None:
+            raise err
         n = len(ids)
         stats = dict(images=n, pairs=n * (n - 1) // 2, matches=0, gpu_s=0.0, db_s=0.0, verified_pairs=0, ranks=world)
         if n < 2:
             return stats
         my_pairs = vd.pairs_for_rank(n, rank, world)
         t1 = time.perf_counter()
-        if D == 0:
-            lists = [np.zeros((0, 2), np.uint32) for _ in my_pairs]          # no descriptors anywhere: every pair is empty
-        else:
-            lists = match_fn(block, counts, my_pairs, max_ratio, max_distance, cross_check)
+        err, lists, results = None, [], None
+        try:
+            if D == 0:
+                lists = [np.zeros((0, 2), np.uint32) for _ in my_pairs]      # no descriptors anywhere: every pair is empty
+            else:
+                lists = match_fn(block, counts, my_pairs, max_ratio, max_distance, cross_check)
+                if verify:                                                     # this rank verifies the pairs it matched
+                    vdev = device if (verify_fn is not None or torch.cuda.is_available()) else "cpu"
+                    results = verify_pair_lists(_unpack_keypoints(kp_arr, kp_cnt), ids, my_pairs, lists, device=vdev,
+                                                verify_fn=verify_fn)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if distributed:
+            vd.raise_if_any_failed(err, "matching / verification")
+        elif err is not None:
+            raise err
         stats["gpu_s"] = time.perf_counter() - t1
         merged = vd.gather_pair_lists(my_pairs, lists, dst=0) if distributed else \
             {(int(a), int(b)): m for (a, b), m in zip(my_pairs, lists)}
+        verified = None
+        if results is not None:
+            verified = vd.gather_pair_results(my_pairs, results, dst=0) if distributed else \
+                {(int(a), int(b)): r for (a, b), r in zip(my_pairs, results)}
+        err = None
         if rank == 0:
-            t2 = time.perf_counter()
-            for a, b in exhaustive_pairs(n).numpy():                           # COLMAP's pair order, whatever rank matched it
-                m = merged[(int(a), int(b))]
-                db.write_matches(ids[a], ids[b], m, commit=False)
-                stats["matches"] += len(m)
-            db.commit()
-            if verify and D != 0:
-                from .two_view import verify_database_pairs
-
-                stats["verified_pairs"] = verify_database_pairs(db, ids, merged, device=device if torch.cuda.is_available() else "cpu")
-            stats["db_s"] = time.perf_counter() - t2
+            try:
+                t2 = time.perf_counter()
+                for a, b in exhaustive_pairs(n).numpy():                       # COLMAP's pair order, whatever rank matched it
+                    m = merged[(int(a), int(b))]
+                    db.write_matches(ids[a], ids[b], m, commit=False)
+                    stats["matches"] += len(m)
+                db.commit()
+                if verified is not None:
+                    stats["verified_pairs"] = write_two_view_rows(db, ids, verified)
+                stats["db_s"] = time.perf_counter() - t2
+            except Exception as e:  # noqa: BLE001
+                err = e
         if distributed:
-            torch.distributed.barrier()
+            vd.raise_if_any_failed(err, "writing the database")
+            stats = vd.broadcast_object(stats, 0)                              # every rank returns rank 0's totals
+        elif err is not None:
+            raise err
         stats["total_s"] = time.perf_counter() - t0
         logger.info("matched %d pairs (%d matches) on %d rank(s): gpu %.3f s, db %.3f s", stats["pairs"], stats["matches"],
                     world, stats["gpu_s"], stats["db_s"])

@@ -219,21 +219,42 @@ def verify_pairs(keypoints, pair_images, pair_ids, match_lists, device="cuda", n
     return results
 
 
-def verify_database_pairs(db, ids, merged, device="cuda") -> int:
-    """Verify every matched pair of a database that is open for writing and write its two_view_geometries row
-    (one per pair, as COLMAP does [recalled]: pairs that fail keep config DEGENERATE and zero inlier rows).
-    `merged`: {(a, b): uint32 (M, 2)} with a < b image indices into `ids`.  Returns the number of verified pairs."""
+def read_keypoints_by_index(db, ids):
+    """{image index: float32 (N, >= 2)} for every image of `ids` (empty array where the database has no keypoints)."""
     kps = {}
     for k, image_id in enumerate(ids):
-        kp = db.read_keypoints(image_id)
+        kp = None if image_id is None else db.read_keypoints(image_id)
         kps[k] = np.zeros((0, 2), np.float32) if kp is None else np.asarray(kp, np.float32)
-    pair_images = sorted(merged)
+    return kps
+
+
+def verify_pair_lists(kps, ids, pairs, lists, device="cuda", verify_fn=None):
+    """This rank's share of the verification: pairs (P, 2) image indices with their match lists -> one result dict per
+    pair (verify_pairs' format).  The sampler is seeded by the COLMAP pair id, so a pair's result does not depend on the
+    rank that verifies it.  `verify_fn(kps, pair_images, pair_ids, lists)` replaces verify_pairs in the CPU tests."""
+    pair_images = [(int(a), int(b)) for a, b in pairs]
     pids = [pair_id_of(ids[a], ids[b]) for a, b in pair_images]
-    lists = [merged[p] for p in pair_images]
-    res = verify_pairs(kps, pair_images, pids, lists, device=device)
+    if verify_fn is not None:
+        return verify_fn(kps, pair_images, pids, lists)
+    return verify_pairs(kps, pair_images, pids, lists, device=device)
+
+
+def write_two_view_rows(db, ids, results) -> int:
+    """results {(a, b): verify_pairs result} -> two_view_geometries rows in pair order (one per matched pair, as COLMAP
+    does [recalled]: pairs that fail keep config DEGENERATE and zero inlier rows).  Returns the number of verified pairs."""
     n_ok = 0
-    for (a, b), r in zip(pair_images, res):
+    for (a, b) in sorted(results):
+        r = results[(a, b)]
         db.write_two_view_geometry(ids[a], ids[b], r["inlier_matches"], r["config"], F=r["F"], H=r["H"], commit=False)
         n_ok += r["config"] != CONFIG_DEGENERATE
     db.commit()
     return int(n_ok)
+
+
+def verify_database_pairs(db, ids, merged, device="cuda", verify_fn=None) -> int:
+    """Single-process form: verify every matched pair of a database that is open for writing and write its rows.
+    `merged`: {(a, b): uint32 (M, 2)} with a < b image indices into `ids`.  Returns the number of verified pairs."""
+    pairs = sorted(merged)
+    res = verify_pair_lists(read_keypoints_by_index(db, ids), ids, pairs, [merged[p] for p in pairs], device=device,
+                            verify_fn=verify_fn)
+    return write_two_view_rows(db, ids, dict(zip(pairs, res)))

@@ -6,15 +6,18 @@ torch.distributed process group with more than one rank exists (one process per 
      image before any inference (reference vit_extractor.py:739: a failed image still has its row);
   3. every rank extracts its block on its own GPU; the per-image uint8 descriptor blocks, padded to a common
      (n_max, D), are ALL-GATHERED (the one collective of the data path, RCCL over xGMI), keypoints with them;
-  4. rank 0 writes keypoints / descriptors; the exhaustive pair list is dealt round-robin, every rank matches its
-     share from the gathered blocks (no database read), the match lists are gathered to rank 0, which writes them
-     and the two-view geometries.
+  4. rank 0 writes keypoints / descriptors; the exhaustive pair list is dealt round-robin, every rank matches
+     and geometrically verifies its share from the gathered blocks and keypoints (no database read); the match lists
+     and two-view geometries are gathered to rank 0, which writes them in pair order.
+An error on any rank (rank 0's database included) is raised on every rank instead of leaving the others in a collective
+(dist.raise_if_any_failed).
 The reference is single-process; there is no counterpart to cite beyond the plugin API it keeps
 (`extract(image_dir, db_path, camera_model, camera_params)`, run_pipeline.py:343, and the match call :351-363).
 
 `feature_fn(list of BGR arrays) -> list of (keypoints (N, k) float32, descriptors (N, D) uint8)` and
-`match_fn(blocks, counts, pairs, max_ratio, max_distance, cross_check) -> list of match lists` default to the HIP
-extractor / matcher; the world-size-2 gloo test passes host stand-ins (there is no GPU in that container).
+`match_fn(blocks, counts, pairs, max_ratio, max_distance, cross_check) -> list of match lists` and
+`verify_fn(keypoints, pair_images, pair_ids, lists) -> list of results` default to the HIP extractor / matcher / scorer;
+the world-size-2 gloo test passes host stand-ins (there is no GPU in that container).
 """
 import logging
 from pathlib import Path
@@ -30,7 +33,7 @@ logger = logging.getLogger(__name__)
 
 
 def run_sharded(image_dir, db_path, camera_model, camera_params=None, feature_fn=None, matching_options=None,
-                match_fn=None, do_matching=True, verify=True, device="cuda", batch_size=50) -> dict:
+                match_fn=None, do_matching=True, verify=True, device="cuda", batch_size=50, verify_fn=None) -> dict:
     from ..database.colmap_db import Camera, ColmapDatabase
     from ..matching.exhaustive import _sift_options, hip_match_blocks
 
@@ -91,24 +94,33 @@ def run_sharded(image_dir, db_path, camera_model, camera_params=None, feature_fn
     stats = dict(images=int(all_readable.sum()), ranks=world, pairs=0, matches=0, verified_pairs=0)
     ids = None
     db = None
+    err = None
+    cnt = all_counts.cpu().numpy()
+    kp_np = all_kps.cpu().numpy()
     if rank == 0:
-        db = ColmapDatabase(str(db_path))
-        height, width = int(shape0[0]), int(shape0[1])
-        if camera_params is None:
-            camera_params = default_camera_params(camera_model, width, height)
-        cam = db.db.write_camera(Camera(model=camera_model, width=width, height=height, params=camera_params))
-        ids = [db.add_image(f.name, camera_id=cam) if all_readable[k] else None for k, f in enumerate(image_files)]
-        cnt = all_counts.cpu().numpy()
-        kp_np, d_np = all_kps.cpu().numpy(), all_desc.cpu().numpy()
-        for k, image_id in enumerate(ids):
-            if image_id is not None and cnt[k] > 0:
-                db.add_keypoints(image_id, kp_np[k, : cnt[k]])
-                db.add_descriptors(image_id, d_np[k, : cnt[k]])
-        db.commit()
+        try:
+            db = ColmapDatabase(str(db_path))
+            height, width = int(shape0[0]), int(shape0[1])
+            if camera_params is None:
+                camera_params = default_camera_params(camera_model, width, height)
+            cam = db.db.write_camera(Camera(model=camera_model, width=width, height=height, params=camera_params))
+            ids = [db.add_image(f.name, camera_id=cam) if all_readable[k] else None for k, f in enumerate(image_files)]
+            d_np = all_desc.cpu().numpy()
+            for k, image_id in enumerate(ids):
+                if image_id is not None and cnt[k] > 0:
+                    db.add_keypoints(image_id, kp_np[k, : cnt[k]])
+                    db.add_descriptors(image_id, d_np[k, : cnt[k]])
+            db.commit()
+        except Exception as e:  # noqa: BLE001 - handed to every rank below
+            err = e
     try:
+        vd.raise_if_any_failed(err, "writing images / features")
         if not do_matching:
             return stats
-        # ---- matching: images with a database row, in id order; pairs dealt round-robin --------------------------------
+        # ---- matching + verification: images with a database row, in id order; pairs dealt round-robin -----------------
+        from ..matching.two_view import verify_pair_lists, write_two_view_rows
+
+        ids = vd.broadcast_object(ids, 0)                                   # pair ids seed the verification sampler
         keep = np.nonzero(all_readable)[0]
         m = len(keep)
         stats["pairs"] = m * (m - 1) // 2
@@ -116,25 +128,35 @@ def run_sharded(image_dir, db_path, camera_model, camera_params=None, feature_fn
         r_, d_, c_ = float(sift.max_ratio), float(sift.max_distance), bool(sift.cross_check)
         blocks = all_desc[torch.from_numpy(keep).to(all_desc.device)]
         bcounts = all_counts[torch.from_numpy(keep).to(all_counts.device)]
+        kept_ids = [ids[k] for k in keep]
         my_pairs = vd.pairs_for_rank(m, rank, world)
-        if match_fn is None:
-            lists = hip_match_blocks(blocks, bcounts, my_pairs, r_, d_, c_, device=device)
-        else:
-            lists = match_fn(blocks.cpu().numpy(), bcounts.cpu().numpy(), my_pairs, r_, d_, c_)
+        err, lists, results = None, [], None
+        try:
+            if match_fn is None:
+                lists = hip_match_blocks(blocks, bcounts, my_pairs, r_, d_, c_, device=device)
+            else:
+                lists = match_fn(blocks.cpu().numpy(), bcounts.cpu().numpy(), my_pairs, r_, d_, c_)
+            if verify:                                                          # every rank verifies the pairs it matched
+                kps = {i: kp_np[k, : cnt[k], :2] for i, k in enumerate(keep)}
+                results = verify_pair_lists(kps, kept_ids, my_pairs, lists, device=device, verify_fn=verify_fn)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        vd.raise_if_any_failed(err, "matching / verification")
         merged = vd.gather_pair_lists(my_pairs, lists, dst=0)
+        verified = vd.gather_pair_results(my_pairs, results, dst=0) if results is not None else None
+        err = None
         if rank == 0:
-            kept_ids = [ids[k] for k in keep]
-            for (a, b), lst in sorted(merged.items()):
-                db.db.write_matches(kept_ids[a], kept_ids[b], lst, commit=False)
-                stats["matches"] += len(lst)
-            db.commit()
-            if verify:
-                from ..matching.two_view import verify_database_pairs
-
-                stats["verified_pairs"] = verify_database_pairs(db.db, kept_ids, merged, device=device)
-        if vd.is_distributed():
-            torch.distributed.barrier()
-        return stats
+            try:
+                for (a, b), lst in sorted(merged.items()):
+                    db.db.write_matches(kept_ids[a], kept_ids[b], lst, commit=False)
+                    stats["matches"] += len(lst)
+                db.commit()
+                if verified is not None:
+                    stats["verified_pairs"] = write_two_view_rows(db.db, kept_ids, verified)
+            except Exception as e:  # noqa: BLE001
+                err = e
+        vd.raise_if_any_failed(err, "writing matches / two-view geometries")
+        return vd.broadcast_object(stats, 0)                                    # every rank returns rank 0's totals
     finally:
         if db is not None:
             db.db.close()
