@@ -217,3 +217,135 @@ def test_trainable_vit_pipeline_extract_then_match(tmp_path):
         assert h.read_two_view_geometry(1, 2) is not None                                      # one row per matched pair
     assert (tmp_path / "results" / "synthetic" / "boards" / "trainable_vit.json").exists()
     assert (tmp_path / "results" / "synthetic" / "summary.csv").exists()
+
+
+# ---- (d) configs[4] as a CHAIN: ViT-B/14 -> 2048 keypoint targets -> PCA FITTED 768 -> 256 -> matching ---------
+def test_configs4_chain_vitb_pca_fit_then_exhaustive_matching(tmp_path, capsys):
+    """DTU-size frames (1600 x 1200 -> 85 x 114 token grid, reference scripts/run_DTU_vit.sh:4) so that the first image
+    keeps more than 256 keypoints and the reference's PCA-FIT branch really runs (vit_extractor.py:601-618; at 640 x 480
+    it lands in the random-projection branch :633-639).  Checked: tokens against the float32 module path on the same
+    weights, the fitted matrix (orthonormal, spans the top-256 principal subspace of the first image's centred
+    descriptors), selection bit-exact on the GPU's own score map with the FITTED matrix handed to the oracle as input,
+    then extract() -> database -> match_exhaustive (two batch shards, 2048-target blocks) against the C oracle."""
+    from vit_colmap_amd.database import ColmapDatabase
+    from vit_colmap_amd.features import hip_select as hs
+    from vit_colmap_amd.features.vit_extractor import ViTExtractor
+    from vit_colmap_amd.matching import match_exhaustive
+    from vit_colmap_amd.utils import image_io
+
+    W5, H5, n_img = 1600, 1200, 24
+    ex = ViTExtractor(model_name="dinov2_vitb14", num_keypoints=2048, descriptor_dim=256)
+    assert ex.descriptor_projection is None
+    imgs = [synthetic_image(k, W5, H5) for k in range(n_img // 2)]
+    rs = np.random.RandomState(4)
+    for k in range(n_img // 2):      # second half: the first half shifted by whole patches (+ a little noise): overlapping views
+        sh = np.roll(imgs[k], (14 * (1 + k % 3), 28), (0, 1)).astype(np.int16) + rs.randint(-2, 3, imgs[k].shape)
+        imgs.append(np.clip(sh, 0, 255).astype(np.uint8))
+    # (1) tokens of two frames: bf16 product path vs the float32 module path (same seeded weights) on the GPU
+    d2 = torch.from_numpy(np.stack(imgs[:2])).cuda()
+    tokens, hp, wp = ex._tokens(d2)
+    assert (hp, wp) == (85, 114) and tuple(tokens.shape) == (2, 85 * 114, 768)
+    ref = ViTExtractor(model_name="dinov2_vitb14", num_keypoints=2048, descriptor_dim=256, precision="fp32", seed=ex.seed)
+    ref_tokens, _, _ = ref._tokens(d2)
+    rel = ((tokens.float() - ref_tokens.float()).norm() / ref_tokens.float().norm()).item()
+    with capsys.disabled():
+        print(f"\n[configs[4] chain, ViT-B/14 at 85 x 114 tokens: bf16 vs float32 module] rel L2 {rel:.3e}")
+    assert rel < 2.5e-2
+    del ref, ref_tokens
+    # (2) the projection fit on the first image (M > 256)
+    ex._ensure_projection(tokens, hp, wp, (W5, H5), (wp * 14, hp * 14))
+    P = ex.descriptor_projection
+    assert tuple(P.shape) == (768, 256)
+    first = hs.dense_to_sparse(tokens[:1], hp, wp, (W5, H5), (wp * 14, hp * 14), 2048, "harris", None, want_f32=False)
+    m = int(first["count"][0])
+    assert m > 256, f"the fit branch needs more keypoints than descriptor_dim, got {m}"
+    yx = first["yx"][0, :m].long()
+    dsc = tokens[0].float()[yx[:, 0] * wp + yx[:, 1]].double().cpu().numpy()
+    cen = dsc - dsc.mean(axis=0, keepdims=True)
+    Pn = P.double().cpu().numpy()
+    assert np.abs(Pn.T @ Pn - np.eye(256)).max() < 1e-3                                  # orthonormal columns (float32 SVD)
+    sv = np.linalg.svd(cen, compute_uv=False)
+    captured = (cen @ Pn) ** 2
+    assert abs(captured.sum() - (sv[:256] ** 2).sum()) <= 1e-3 * (sv ** 2).sum()        # the top-256 principal subspace
+    # (3) selection + projected descriptors, bit-exact / 1e-3 against the oracle chain with the FITTED matrix as input
+    res = hs.dense_to_sparse(tokens, hp, wp, (W5, H5), (wp * 14, hp * 14), 2048, "harris", P, want_f32=True)
+    score = res["score"].cpu().numpy()
+    proj_np = P.float().cpu().numpy()
+    got = tokens.float().cpu()
+    for i in range(2):
+        fmap = np.ascontiguousarray(got[i].numpy().T.reshape(768, hp, wp))
+        o = so.dense_to_sparse(fmap, (W5, H5), (wp * 14, hp * 14), 2048, 256, "harris", proj_np, score=score[i])
+        n = int(res["count"][i])
+        assert n == len(o["keypoints"]) > 256
+        assert np.array_equal(res["yx"][i, :n].cpu().numpy(), o["coords"])
+        assert np.array_equal(res["keypoints"][i, :n].cpu().numpy(), o["keypoints"])
+        f = res["desc_f32"][i, :n].cpu().numpy()
+        assert np.abs(f - o["desc_f32"]).max() <= 1e-3 * np.abs(o["desc_f32"]).max()
+        assert np.abs(res["desc_u8"][i, :n].cpu().numpy().astype(int) - o["desc_u8"].astype(int)).max() <= 1
+    # (4) the directory API over all 24 frames, then exhaustive matching through the database vs the C oracle
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    for k, im in enumerate(imgs):
+        image_io.imwrite(img_dir / f"im_{k:02d}.bmp", im)
+    ex.extract(img_dir, tmp_path / "c5.db", "SIMPLE_PINHOLE")
+    stats = match_exhaustive(database_path=str(tmp_path / "c5.db"), verify=False)
+    assert stats["images"] == n_img and stats["pairs"] == n_img * (n_img - 1) // 2
+    with ColmapDatabase.open_database(str(tmp_path / "c5.db")) as h:
+        ids = [im.image_id for im in h.read_all_images()]
+        descs = [h.read_descriptors(i) for i in ids]
+        assert all(dd is not None and dd.shape[1] == 256 and dd.shape[0] > 256 for dd in descs)
+        n_max = max(len(dd) for dd in descs)
+        block = np.zeros((n_img, n_max, 256), np.uint8)
+        counts = np.array([len(dd) for dd in descs], np.int32)
+        for k, dd in enumerate(descs):
+            block[k, : len(dd)] = dd
+        pairs = mo.exhaustive_pairs(n_img)
+        om, oc, _ = c_oracle.match_pairs(block, counts, pairs)
+        total = 0
+        for p, (a, b) in enumerate(pairs):
+            mm = h.read_matches(ids[a], ids[b])
+            mm = np.zeros((0, 2), np.uint32) if mm is None else mm
+            assert np.array_equal(mm, om[p, : oc[p]]), f"pair {a},{b}"
+            total += len(mm)
+    assert total > 200, "the shifted copies must match their originals"
+    with capsys.disabled():
+        print(f"[configs[4] chain] {n_img} frames of {W5}x{H5}: {int(counts.mean())} keypoints per image (max {n_max}), "
+              f"{stats['pairs']} pairs, {total} matches, all lists equal to the C oracle")
+
+
+# ---- (e) drop-in fidelity of the bf16 product path (VERDICT r02 #8): a diagnostic, not a bit-exactness claim --------------------
+def test_bf16_product_path_fidelity_against_the_float32_chain(capsys):
+    """What a user swapping the extractor in would ask: on the bench's images, how far are the keypoints and descriptors
+    of the bf16 product path (hand-written kernels) from the float32 chain — float32 oracle tokens on the same weights,
+    oracle selection and descriptors?  Reported and loosely bounded; the numbers go into DESIGN.md §2."""
+    from vit_colmap_amd.features.vit_extractor import ViTExtractor
+    from vit_colmap_amd.vit import build_dinov2
+
+    n_img = 6
+    ex = ViTExtractor(model_name="dinov2_vits14", num_keypoints=512, descriptor_dim=384)
+    imgs = np.stack([synthetic_image(k) for k in range(n_img)])
+    res = ex.extract_device(torch.from_numpy(imgs).cuda())
+    ref_tokens = _oracle_tokens(build_dinov2("dinov2_vits14").init_random(ex.seed), imgs).numpy()
+    ious, cosines, u8_diff, u8_n, counts = [], [], 0, 0, []
+    for i in range(n_img):
+        fmap = np.ascontiguousarray(ref_tokens[i].T.reshape(384, 34, 45))
+        o = so.dense_to_sparse(fmap, (640, 480), (630, 476), 512, 384, "harris")
+        n = int(res["count"][i])
+        g_yx = {tuple(v) for v in res["yx"][i, :n].cpu().numpy().tolist()}
+        o_yx = {tuple(v) for v in np.asarray(o["coords"]).tolist()}
+        common = g_yx & o_yx
+        ious.append(len(common) / max(len(g_yx | o_yx), 1))
+        counts.append((n, len(o_yx)))
+        gi = {tuple(v): k for k, v in enumerate(res["yx"][i, :n].cpu().numpy().tolist())}
+        oi = {tuple(v): k for k, v in enumerate(np.asarray(o["coords"]).tolist())}
+        gd, od = res["desc_u8"][i, :n].cpu().numpy(), o["desc_u8"]
+        for c in common:
+            a, b = gd[gi[c]].astype(np.float64), od[oi[c]].astype(np.float64)
+            cosines.append(float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-12)))
+            u8_diff += int((gd[gi[c]] != od[oi[c]]).sum())
+            u8_n += a.size
+    iou, cos_med, cos_min, frac = float(np.mean(ious)), float(np.median(cosines)), float(np.min(cosines)), u8_diff / max(u8_n, 1)
+    with capsys.disabled():
+        print(f"\n[bf16 product path vs float32 chain, {n_img} bench images] keypoint-set IoU {iou:.3f} (counts gpu/oracle {counts}), "
+              f"descriptor cosine on common keypoints median {cos_med:.5f} min {cos_min:.5f}, uint8 entries that differ {frac:.3%}")
+    assert iou > 0.5 and cos_med > 0.99 and len(cosines) > 100

@@ -1,4 +1,5 @@
 """GPU end-to-end tests through the reference's own interfaces (plugin API, DB contract)."""
+import os
 import sqlite3
 
 import numpy as np
@@ -218,3 +219,39 @@ def test_extract_then_match_full_path(tmp_path):
         for a in range(6):
             for b in range(a + 1, 6):
                 assert np.array_equal(h.read_matches(a + 1, b + 1), mo.match_pair(descs[a], descs[b]))
+
+
+def test_rccl_one_rank_group_moves_device_descriptor_blocks():
+    """RCCL itself (torch.distributed backend "nccl" on ROCm) executes on the visible GPU: a one-rank
+    process group, the data path's collective (dist.all_gather_descriptors -> all_gather_into_tensor on device tensors)
+    and the error hand-shake's all_reduce.  One rank is all a one-GPU box allows (RCCL refuses two ranks on one device);
+    the multi-rank logic is covered by the world-size-2 gloo tests."""
+    import socket
+
+    import torch.distributed as dist
+
+    from vit_colmap_amd import dist as vd
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl" and not vd.is_distributed()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        desc = torch.randint(0, 256, (50, 512, 384), dtype=torch.uint8, device="cuda", generator=g)
+        counts = torch.randint(0, 513, (50,), dtype=torch.int32, device="cuda", generator=g)
+        all_desc, all_counts = vd.all_gather_descriptors(desc, counts, force_collective=True)
+        torch.cuda.synchronize()
+        assert all_desc.data_ptr() != desc.data_ptr()                  # went through the collective, not the early return
+        assert torch.equal(all_desc, desc) and torch.equal(all_counts, counts)
+        t = torch.tensor([7], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == 7
+        print(f"[RCCL one-rank smoke] all_gather_into_tensor of {desc.numel() / 1e6:.1f} MB uint8 + counts on {torch.cuda.get_device_name(0)}: ok")
+    finally:
+        dist.destroy_process_group()

@@ -53,10 +53,12 @@ def pair_index(n_images: int, a, b):
     return a * (2 * n_images - a - 1) // 2 + (b - a - 1)
 
 
-def all_gather_descriptors(desc: torch.Tensor, counts: torch.Tensor):
+def all_gather_descriptors(desc: torch.Tensor, counts: torch.Tensor, force_collective: bool = False):
     """desc uint8 (n_local, n_max, D), counts int32 (n_local,) -> the same for all ranks' images,
-    concatenated in rank order.  Every rank must pass the same n_local (pad with count 0)."""
-    if not is_distributed():
+    concatenated in rank order.  Every rank must pass the same n_local (pad with count 0).
+    force_collective: run the collective even in a one-rank group (the single-GPU RCCL smoke test: the same
+    all_gather_into_tensor calls on device tensors as a multi-GPU run, world size 1)."""
+    if not is_distributed() and not (force_collective and dist.is_available() and dist.is_initialized()):
         return desc, counts
     world = dist.get_world_size()
     all_desc = torch.empty((world * desc.shape[0],) + tuple(desc.shape[1:]), dtype=desc.dtype, device=desc.device)

@@ -20,6 +20,7 @@ Differences from the reference, all deliberate:
     are reproducible; if it is not, it is fitted on the first image as the reference does, but
     with a seeded generator for the random branch.
 """
+import os
 from pathlib import Path
 from typing import Optional
 
@@ -190,6 +191,29 @@ class ViTExtractor(BaseExtractor):
             self.descriptor_projection = p.to(self.device)
             print(f"Initialized random projection (insufficient samples): {C} -> {self.descriptor_dim}")
 
+    # Batch shards on HIP streams (see vit/dinov2.py `_run_sharded`): at this level the WHOLE device path of a shard —
+    # preprocessing, patch embedding, the block stack, the final norm, selection and descriptors — runs on the shard's
+    # stream, so that the small-grid tail of one shard (selection: one workgroup per image) and the head of the next
+    # step's other shard overlap with the full-chip ViT kernels of its sibling.  VITCOLMAP_VIT_SHARDS / `batch_shards`
+    # as for the model (default 2, batches of >= 16 images; 1 = single stream).
+    batch_shards = None
+
+    def _shard_bounds(self, B):
+        import os
+
+        k = self.batch_shards if self.batch_shards is not None else int(os.environ.get("VITCOLMAP_VIT_SHARDS", "2"))
+        if k <= 1 or B < 8 * k or not getattr(self.model, "_hip", None):
+            return None
+        return [B * i // k for i in range(k + 1)]
+
+    def _extract_one(self, images_bgr, hw):
+        h, w, h_new, w_new = hw
+        tokens, hp, wp = self._tokens(images_bgr)
+        self._ensure_projection(tokens, hp, wp, (w, h), (w_new, h_new))
+        proj = self.descriptor_projection if tokens.shape[-1] > self.descriptor_dim else None
+        return hip_select.dense_to_sparse(tokens, hp, wp, (w, h), (w_new, h_new), self.num_keypoints,
+                                          self.detection_method, proj)
+
     @torch.inference_mode()
     def extract_device(self, images_bgr: torch.Tensor):
         """Device-resident batch API: uint8 (B, h, w, 3) already in HBM -> dict of GPU tensors
@@ -197,12 +221,34 @@ class ViTExtractor(BaseExtractor):
         This is what bench.py and the multi-GPU path call; nothing is copied to the host."""
         self._require_gpu()
         B, h, w, _ = images_bgr.shape
-        h_new, w_new = (h // PATCH) * PATCH, (w // PATCH) * PATCH
-        tokens, hp, wp = self._tokens(images_bgr)
-        self._ensure_projection(tokens, hp, wp, (w, h), (w_new, h_new))
-        proj = self.descriptor_projection if tokens.shape[-1] > self.descriptor_dim else None
-        return hip_select.dense_to_sparse(tokens, hp, wp, (w, h), (w_new, h_new), self.num_keypoints,
-                                          self.detection_method, proj)
+        hw = (h, w, (h // PATCH) * PATCH, (w // PATCH) * PATCH)
+        bounds = self._shard_bounds(B)
+        needs_fit = self.model.arch.dim > self.descriptor_dim and self.descriptor_projection is None
+        if bounds is None or needs_fit:       # (the projection is fitted once, on the first image: vit_extractor.py:601-648)
+            return self._extract_one(images_bgr, hw)
+        dev = images_bgr.device
+        if getattr(self, "_shard_streams", None) is None or self._shard_streams[0] != (dev, len(bounds)):
+            self._shard_streams = ((dev, len(bounds)), [torch.cuda.Stream(device=dev) for _ in range(len(bounds) - 2)])
+        cur = torch.cuda.current_stream(dev)
+        streams = [cur] + self._shard_streams[1]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        inner = self.model.batch_shards
+        self.model.batch_shards = 1           # the shards are cut here, not inside the block loop
+        parts = []
+        try:
+            for i, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    if s is not cur:
+                        s.wait_event(ready)
+                    parts.append(self._extract_one(images_bgr[bounds[i]:bounds[i + 1]], hw))
+        finally:
+            self.model.batch_shards = inner
+        for s in streams[1:]:                 # join before anything of the side streams is read on the caller's stream
+            done = torch.cuda.Event()
+            done.record(s)
+            cur.wait_event(done)
+        return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
 
     @torch.inference_mode()
     def _run_batch(self, images_bgr_np):
@@ -223,6 +269,52 @@ class ViTExtractor(BaseExtractor):
         desc = res["desc_u8"].cpu().numpy()
         return [(kps[i, : counts[i]].astype(np.float32).copy(), desc[i, : counts[i]].copy())
                 for i in range(len(images_bgr_np))]
+
+    # ---- asynchronous form of _run_batch: what extract() pipelines --------------------------------------------
+    def _staging(self, slot, shape):
+        """Pinned host staging buffer `slot` (0 / 1) for a uint8 batch of `shape` (grown, never shrunk)."""
+        bufs = self.__dict__.setdefault("_pinned_in", {})
+        n = int(np.prod(shape))
+        if slot not in bufs or bufs[slot].numel() < n:
+            bufs[slot] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        return bufs[slot][:n].view(shape)
+
+    @torch.inference_mode()
+    def _launch_batch(self, images_bgr_np):
+        """Enqueue upload + extraction + read-back of one batch of equal-size frames on the extractor's I/O stream and
+        return a handle at once (no host wait)."""
+        self._require_gpu()
+        h, w = images_bgr_np[0].shape[:2]
+        if (h // PATCH) * PATCH == 0 or (w // PATCH) * PATCH == 0:
+            raise ValueError(f"image {w}x{h} is smaller than one 14x14 patch")
+        if getattr(self, "_io_stream", None) is None:
+            self._io_stream = torch.cuda.Stream(device=self.device)
+            self._io_slot = 0
+        self._io_slot ^= 1
+        n = len(images_bgr_np)
+        host = self._staging(self._io_slot, (n, h, w, 3))
+        hv = host.numpy()
+        for i, im in enumerate(images_bgr_np):
+            hv[i] = im
+        with torch.cuda.stream(self._io_stream):
+            batch = host.to(self.device, non_blocking=True)
+            res = self.extract_device(batch)
+            out = {}
+            for k in ("count", "keypoints", "desc_u8"):
+                dst = torch.empty(res[k].shape, dtype=res[k].dtype, pin_memory=True)
+                dst.copy_(res[k], non_blocking=True)
+                out[k] = dst
+            done = torch.cuda.Event()
+            done.record(self._io_stream)
+        return dict(n=n, out=out, done=done, keep=(batch, res))   # (device tensors stay referenced until the event)
+
+    def _finish_batch(self, handle):
+        """Wait for a launched batch -> list of (keypoints (N, 2) float32, descriptors (N, D) uint8)."""
+        handle["done"].synchronize()
+        counts = handle["out"]["count"].numpy()
+        kps, desc = handle["out"]["keypoints"].numpy(), handle["out"]["desc_u8"].numpy()
+        handle["keep"] = None
+        return [(kps[i, : counts[i]].astype(np.float32).copy(), desc[i, : counts[i]].copy()) for i in range(handle["n"])]
 
     def _run_inference(self, image_bgr: np.ndarray):
         """Single image (vit_extractor.py:106-166): keypoints (N, 2) float32 (x, y) in original-image
@@ -264,32 +356,25 @@ class ViTExtractor(BaseExtractor):
         camera_id = db.db.write_camera(Camera(model=camera_model, width=width, height=height, params=camera_params))
         print(f"Camera ID: {camera_id}\n")
 
-        # ---- batches of equal-size images, in file order ---------------------------------------
-        pending = []  # (image_id, name, array)
+        # ---- batches of equal-size images, in file order, three overlapped stages -----------------------------------
+        # The reference's loop is serial: imread -> inference -> two DB writes per image, the GPU idle during the host
+        # work (vit_extractor.py:729-755).  Here:
+        #   * files are decoded by a small thread pool running ahead of the loop (PIL / OpenCV release the GIL), results
+        #     consumed in file order so image ids stay those of the serial loop;
+        #   * a batch is uploaded from a pinned staging buffer and runs on its own stream without a host wait; its
+        #     keypoints / descriptors come back by asynchronous copies into pinned buffers behind an event;
+        #   * the rows of batch k-1 are written while batch k runs (two staging buffers, one batch in flight).
+        # `add_image` still precedes inference, and a failing batch is re-run image by image so that one bad image never
+        # takes its neighbours with it (vit_extractor.py:739-762).
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
 
-        def flush():
-            if not pending:
-                return
-            t0 = time.perf_counter()
-            try:
-                results = self._run_batch([p[2] for p in pending])
-            except _lib.HipLibraryError:
-                raise                          # a missing GPU / library is not a per-image problem
-            except Exception:                  # isolate the failing image (vit_extractor.py:757-762)
-                results = []
-                for _, name, arr in pending:
-                    try:
-                        results.append(self._run_batch([arr])[0])
-                    except Exception as e:  # noqa: BLE001
-                        import traceback
+        pending = []      # (image_id, name, array): the batch being collected
+        in_flight = []    # at most one launched batch: (items, handle)
 
-                        print(f"  ✗ Error during feature extraction of {name}: {e}")
-                        traceback.print_exc()
-                        results.append(None)
-            if self.device.type == "cuda":
-                torch.cuda.synchronize()
+        def write_rows(items, results):
             t1 = time.perf_counter()
-            for (image_id, name, _), r in zip(pending, results):
+            for (image_id, name, _), r in zip(items, results):
                 if r is None:
                     continue
                 keypoints, descriptors = r
@@ -299,22 +384,88 @@ class ViTExtractor(BaseExtractor):
                     continue
                 db.add_keypoints(image_id, keypoints)
                 db.add_descriptors(image_id, descriptors)
-            self.timings["gpu_s"] += t1 - t0
             self.timings["db_s"] += time.perf_counter() - t1
-            self.timings["images"] += len(pending)
-            pending.clear()
+            self.timings["images"] += len(items)
 
-        for idx, img_file in enumerate(image_files, start=1):
+        def one_by_one(items):                 # isolate the failing image (vit_extractor.py:757-762)
+            results = []
+            for _, name, arr in items:
+                try:
+                    results.append(self._run_batch([arr])[0])
+                except _lib.HipLibraryError:
+                    raise
+                except Exception as e:  # noqa: BLE001
+                    import traceback
+
+                    print(f"  ✗ Error during feature extraction of {name}: {e}")
+                    traceback.print_exc()
+                    results.append(None)
+            return results
+
+        def finish():
+            if not in_flight:
+                return
+            items, handle = in_flight.pop()
             t0 = time.perf_counter()
-            img = first_img if idx == 1 else image_io.imread(img_file)
-            self.timings["decode_s"] += time.perf_counter() - t0
-            if img is None:
-                print(f"[{idx}/{len(image_files)}] {img_file.name}: ⚠ failed to read image, skipping")
-                continue
-            image_id = db.add_image(img_file.name, camera_id=camera_id)  # before inference (:739)
-            if pending and (pending[0][2].shape != img.shape or len(pending) >= self.batch_size):
-                flush()
-            pending.append((image_id, img_file.name, img))
-        flush()
+            try:
+                results = self._finish_batch(handle)
+            except _lib.HipLibraryError:
+                raise
+            except Exception:  # noqa: BLE001
+                results = one_by_one(items)
+            self.timings["gpu_s"] += time.perf_counter() - t0      # host time spent WAITING for the GPU
+            write_rows(items, results)
+
+        def flush():
+            if not pending:
+                return
+            items = list(pending)
+            pending.clear()
+            t0 = time.perf_counter()
+            try:
+                handle = self._launch_batch([p[2] for p in items])   # returns without waiting for the GPU
+            except _lib.HipLibraryError:
+                raise                          # a missing GPU / library is not a per-image problem
+            except Exception:  # noqa: BLE001
+                finish()
+                self.timings["gpu_s"] += time.perf_counter() - t0
+                write_rows(items, one_by_one(items))
+                return
+            self.timings["gpu_s"] += time.perf_counter() - t0
+            finish()                           # the PREVIOUS batch: its rows are written while this one runs
+            in_flight.append((items, handle))
+
+        def decode(path):
+            t0 = time.perf_counter()
+            img = image_io.imread(path)
+            return img, time.perf_counter() - t0
+
+        n_files = len(image_files)
+        workers = max(1, min(8, (os.cpu_count() or 2) - 1))
+        ahead = 2 * self.batch_size
+        with ThreadPoolExecutor(workers) as pool:
+            futures = deque()
+            nxt = 1                            # index (0-based) of the next file to hand to the pool; file 0 is decoded
+            while nxt < n_files and len(futures) < ahead:
+                futures.append(pool.submit(decode, image_files[nxt]))
+                nxt += 1
+            for idx, img_file in enumerate(image_files, start=1):
+                if idx == 1:
+                    img = first_img
+                else:
+                    img, dt = futures.popleft().result()
+                    self.timings["decode_s"] += dt
+                    if nxt < n_files:
+                        futures.append(pool.submit(decode, image_files[nxt]))
+                        nxt += 1
+                if img is None:
+                    print(f"[{idx}/{n_files}] {img_file.name}: ⚠ failed to read image, skipping")
+                    continue
+                image_id = db.add_image(img_file.name, camera_id=camera_id)  # before inference (:739)
+                if pending and (pending[0][2].shape != img.shape or len(pending) >= self.batch_size):
+                    flush()
+                pending.append((image_id, img_file.name, img))
+            flush()
+            finish()
         db.commit()
         print(f"\n{'='*60}\n✓ Feature extraction complete!\n{'='*60}\n")
