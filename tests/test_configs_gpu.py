@@ -288,7 +288,14 @@ def test_configs4_chain_vitb_pca_fit_then_exhaustive_matching(tmp_path, capsys):
     for k, im in enumerate(imgs):
         image_io.imwrite(img_dir / f"im_{k:02d}.bmp", im)
     ex.extract(img_dir, tmp_path / "c5.db", "SIMPLE_PINHOLE")
-    stats = match_exhaustive(database_path=str(tmp_path / "c5.db"), verify=False)
+    # (the reference's quantiser clips negatives, so a descriptor's similarity with ITSELF is ~0.5 = an angle of 1.05 > the
+    # default max_distance 0.7, and with random weights every descriptor resembles every other (ratio test): under the default
+    # options nothing matches; the test switches both tests off in effect (ratio 1.0, distance 1.5: mutual nearest neighbours) so that the
+    # match lists compared with the oracle are not all empty)
+    from vit_colmap_amd.utils.config import MatchingConfig
+
+    wide = MatchingConfig(max_ratio=1.0, max_distance=1.5).to_matching_options()
+    stats = match_exhaustive(database_path=str(tmp_path / "c5.db"), matching_options=wide, verify=False)
     assert stats["images"] == n_img and stats["pairs"] == n_img * (n_img - 1) // 2
     with ColmapDatabase.open_database(str(tmp_path / "c5.db")) as h:
         ids = [im.image_id for im in h.read_all_images()]
@@ -300,7 +307,7 @@ def test_configs4_chain_vitb_pca_fit_then_exhaustive_matching(tmp_path, capsys):
         for k, dd in enumerate(descs):
             block[k, : len(dd)] = dd
         pairs = mo.exhaustive_pairs(n_img)
-        om, oc, _ = c_oracle.match_pairs(block, counts, pairs)
+        om, oc, _ = c_oracle.match_pairs(block, counts, pairs, max_ratio=1.0, max_distance=1.5)
         total = 0
         for p, (a, b) in enumerate(pairs):
             mm = h.read_matches(ids[a], ids[b])
