@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool: build experimental variants of the kernel library (tools/exp/lib_<name>.so)
 # usage: tools/build_variants.sh name1:"-DFLAG1 -DFLAG2" name2:"..."
-# Only matcher.hip is recompiled with the flags (every VC_EXP_* / VC_WAVES / VC_INWAVE_LOOP switch lives
+# Only matcher.hip is recompiled with the flags (every VC_EXP_* / VC2_* / VC_WAVES switch lives
 # there); the other objects are the ones `make -C vit_colmap_amd/csrc` left behind.  FILE=gemm.hip (or
 # attention.hip ...) selects another translation unit for the flags.
 set -e
