@@ -215,10 +215,14 @@ class ViTExtractor(BaseExtractor):
                                           self.detection_method, proj)
 
     @torch.inference_mode()
-    def extract_device(self, images_bgr: torch.Tensor):
+    def extract_device(self, images_bgr: torch.Tensor, input_ready=None):
         """Device-resident batch API: uint8 (B, h, w, 3) already in HBM -> dict of GPU tensors
         (keypoints (B, K, 2) float32, desc_u8 (B, K, D) uint8 zero-padded, count (B,) int32).
-        This is what bench.py and the multi-GPU path call; nothing is copied to the host."""
+        This is what bench.py and the multi-GPU path call; nothing is copied to the host.
+        input_ready: a torch.cuda.Event after which `images_bgr` is valid.  Without it the shards start behind everything
+        the caller's stream has been given so far (the only safe assumption); with it they only wait for that event and
+        their own streams, so consecutive batches pipeline: batch k + 1's ViT kernels start while the caller's stream still
+        holds batch k's concatenation / matching (results are always joined into the caller's stream before they are read)."""
         self._require_gpu()
         B, h, w, _ = images_bgr.shape
         hw = (h, w, (h // PATCH) * PATCH, (w // PATCH) * PATCH)
@@ -227,12 +231,17 @@ class ViTExtractor(BaseExtractor):
         if bounds is None or needs_fit:       # (the projection is fitted once, on the first image: vit_extractor.py:601-648)
             return self._extract_one(images_bgr, hw)
         dev = images_bgr.device
-        if getattr(self, "_shard_streams", None) is None or self._shard_streams[0] != (dev, len(bounds)):
-            self._shard_streams = ((dev, len(bounds)), [torch.cuda.Stream(device=dev) for _ in range(len(bounds) - 2)])
+        n_sh = len(bounds) - 1
+        if getattr(self, "_shard_streams", None) is None or self._shard_streams[0] != (dev, n_sh):
+            self._shard_streams = ((dev, n_sh), [torch.cuda.Stream(device=dev) for _ in range(n_sh)])
         cur = torch.cuda.current_stream(dev)
-        streams = [cur] + self._shard_streams[1]
-        ready = torch.cuda.Event()
-        ready.record(cur)
+        side = self._shard_streams[1]
+        if input_ready is None:               # shard 0 on the caller's stream, the others behind its present position
+            streams = [cur] + side[1:]
+            input_ready = torch.cuda.Event()
+            input_ready.record(cur)
+        else:                                 # every shard on a stream of its own
+            streams = side
         inner = self.model.batch_shards
         self.model.batch_shards = 1           # the shards are cut here, not inside the block loop
         parts = []
@@ -240,14 +249,18 @@ class ViTExtractor(BaseExtractor):
             for i, s in enumerate(streams):
                 with torch.cuda.stream(s):
                     if s is not cur:
-                        s.wait_event(ready)
+                        s.wait_event(input_ready)
                     parts.append(self._extract_one(images_bgr[bounds[i]:bounds[i + 1]], hw))
         finally:
             self.model.batch_shards = inner
-        for s in streams[1:]:                 # join before anything of the side streams is read on the caller's stream
+        for s, part in zip(streams, parts):   # join before anything of the side streams is read on the caller's stream
+            if s is cur:
+                continue
             done = torch.cuda.Event()
             done.record(s)
             cur.wait_event(done)
+            for t in part.values():           # allocated on s, read on cur: the allocator must not hand the block back to s early
+                t.record_stream(cur)
         return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
 
     @torch.inference_mode()
