@@ -90,7 +90,9 @@ def test_attention_structured_values_catch_layout_errors():
 
 @pytest.mark.parametrize("rows,K,N", [(1531 * 2, 384, 1152), (300, 384, 384), (1531, 384, 1536), (1000, 1536, 384),
                                       (1, 64, 128), (129, 768, 2304), (128, 128, 256),
-                                      (1531 * 3, 1536, 384), (4096, 64, 128), (4097, 640, 384)])
+                                      (1531 * 3, 1536, 384), (4096, 64, 128), (4097, 640, 384),
+                                      # the 256 x 256 tile kernel (n_out % 256 == 0, >= 1024 rows): ragged last row tile, one and many K steps
+                                      (1531 * 2, 768, 2304), (1024, 64, 256), (1025, 3072, 768), (2047, 768, 768), (5000, 1024, 4096)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_linear_matches_float32_reference(rows, K, N, epi):
     """Hand-written bf16 GEMM + fused epilogue (through the C ABI) vs the float32 evaluation of the same bf16 data."""

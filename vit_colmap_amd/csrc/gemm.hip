@@ -207,6 +207,266 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
 
 
 // =====================================================================================================
+// 256 x 256 tile for the wide layers (ViT-B / ViT-L: n_out % 256 == 0).  The 128 x 128 kernel above moves (128 + 128) x 64 x 2
+// bytes through L2 -> LDS per 128 x 128 x 64 MACs, two workgroups per CU do so independently, and every K step ends in a
+// vmcnt(0) + barrier: measured bound by that at ~28 % of the matrix peak (the library reaches 35-50 % on the
+// ViT-B shapes).  This kernel follows the guide's 256^2 eight-phase structure (cdna_hip_programming.md §5):
+//   * ONE workgroup of 8 waves per CU owns a 256 x 256 tile: waves 2 (token halves, `wr`) x 4 (feature quarters, `wc`); per
+//     wave D^T[64 features][128 tokens] = 4 x 8 accumulator tiles of v_mfma_f32_16x16x32_bf16 (128 VGPRs);
+//   * a 64-deep K tile is computed in FOUR PHASES, one 32-feature x 64-token quadrant (16 MFMAs) each, in the order
+//     (f0,t0) (f1,t0) (f1,t1) (f0,t1): a phase re-reads from LDS only the operand half that changes (W half: 4 ds_read_b128,
+//     x half: 8), the W0 fragments stay in registers for the fourth;
+//   * the two waves of a SIMD (w and w + 4) run half a phase apart: between two barriers one of them is in its MFMA cluster,
+//     the other in its memory cluster (fragment reads + its LDS-DMA pieces) — the matrix pipe always has a wave that does
+//     nothing but feed it (two barriers per phase, waves 4-7 one barrier late);
+//   * staging is cut into UNITS of 16 KiB = the rows one phase starts to need: X0 (token rows [0,64) of both wave rows), W0
+//     (feature rows [0,32) of all four wave columns), W1, X1, in that order, one unit (2 pieces of 1 KiB per wave) issued
+//     per phase, SIX units ahead, into 2 buffers x 4 units = 128 KiB; one counted wait per K tile (vmcnt(4): two units
+//     stay in flight across the barriers) in the fourth phase retires the next K tile.  Hazards, with the half-phase lag
+//     counted in: a unit is first read two barriers after every wave's wait for it, and restaged at least TWO phases after
+//     its last fragment read was issued (X0: read in phase 0, restaged in phase 2; W0 0 / 3; W1 1 / 0 of the next K tile;
+//     X1 2 / 1), so the lgkmcnt(0) for a phase's reads can sit behind the barrier, at the head of the MFMA cluster, where
+//     the read latency overlaps the partner's last MFMAs instead of lengthening the memory cluster.
+constexpr int G2M = 256, G2N = 256;
+constexpr int kUnit2 = 128 * 128;         // 16 KiB: 128 rows x 64 k
+constexpr int kBuf2 = 4 * kUnit2;         // X0 | W0 | W1 | X1
+constexpr int G256_LDS = 2 * kBuf2;       // 128 KiB
+constexpr int kAhead2 = 6;                // units issued ahead of the phase that runs
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W,
+                                                         const __bf16* __restrict__ bias, const __bf16* __restrict__ res,
+                                                         __bf16* __restrict__ out, int M, int N, int K, int n_tiles_n,
+                                                         int n_tiles) {
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds2[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nk = K / BK;
+  const int n_units = 4 * nk;
+  // Persistent workgroups (one per CU) walk the tile list.  (Measured and dropped: starting them up to one tile-time apart so
+  // that epilogues do not coincide — the output writes are not a shared-HBM burst problem; every start delay came back as
+  // added time, 1268 -> 1344 us per ViT-B layer.)
+  for (int slot = blockIdx.x; slot < n_tiles; slot += gridDim.x) {
+  int tile;
+  {
+    const int xcd = slot & 7, idx = slot >> 3;
+    const int q = n_tiles >> 3, r = n_tiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / n_tiles_n, tn = tile - tm * n_tiles_n;
+  const int m0 = tm * G2M, n0 = tn * G2N;
+
+  // ---- staging: unit u = 4 t + j of K tile t; j = 0: X0, 1: W0, 2: W1, 3: X1.  Wave w issues pieces 2w, 2w+1 (8 unit rows each).
+  // unit row rho -> tile row:  X_h: rho < 64 ? rho + 64 h : 128 + (rho - 64) + 64 h;   W_h: (rho >> 5) * 64 + 32 h + (rho & 31)
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds2[0]);
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+  uint32_t voffx[2][2], voffw[2];          // per-lane byte offsets from X / W (+ k offset of the K tile added as a scalar)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rho = (wave * 2 + i) * 8 + prow;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int xr = (rho < 64 ? rho : 128 + (rho - 64)) + 64 * h;
+      voffx[h][i] = (uint32_t)(((size_t)min(m0 + xr, M - 1) * K + pchunk * 8) * 2 - (size_t)min(m0, M - 1) * K * 2);
+    }
+    const int wrow = (rho >> 5) * 64 + (rho & 31);
+    voffw[i] = (uint32_t)(((size_t)wrow * K + pchunk * 8) * 2);
+  }
+  const char* const xbase = (const char*)(X + (size_t)min(m0, M - 1) * K);
+  const char* const wbase = (const char*)(W + (size_t)n0 * K);
+  const size_t whalf = (size_t)32 * K * 2;
+  auto issue = [&](int u) {
+    if (u >= n_units) return;
+    const int t = u >> 2, j = u & 3;
+    const char* sb = (j == 0 || j == 3) ? xbase + (size_t)t * (BK * 2) : wbase + (size_t)t * (BK * 2) + (j == 2 ? whalf : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t vo = j == 0 ? voffx[0][i] : (j == 3 ? voffx[1][i] : voffw[i]);
+      const uint32_t dst = lds0 + (uint32_t)(t & 1) * kBuf2 + (uint32_t)j * kUnit2 + (uint32_t)(wave * 2 + i) * 1024u;
+      uint32_t keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %2\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(vo), "s"(sb), "s"(dst)
+          : "memory");
+    }
+  };
+
+  v4f acc[4][8];   // [feature block of 16][token block of 16]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing inside a unit: lane reads unit row (block * 16 + fr), 16-byte chunk (4 ks + fq) ^ (row & 7)
+  const int fr = lane & 15, fq = lane >> 4;
+  uint32_t xoff[2], woff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ks * 4 + fq;
+    xoff[ks] = (uint32_t)(wr * 64 + fr) * 128u + (uint32_t)((ch ^ (fr & 7)) << 4);
+    woff[ks] = (uint32_t)(wc * 32 + fr) * 128u + (uint32_t)((ch ^ (fr & 7)) << 4);
+  }
+  v8bf xf[2][4], wf[2][2][2];   // x fragments of the current token half [ks][block]; W fragments [feature half][ks][block]
+
+  auto read_x = [&](const uint8_t* buf, int th) {
+    const uint8_t* u = buf + (th == 0 ? 0 : 3) * kUnit2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xf[ks][b] = *(const v8bf*)(u + xoff[ks] + b * 2048);
+  };
+  auto read_w = [&](const uint8_t* buf, int fh) {
+    const uint8_t* u = buf + (1 + fh) * kUnit2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) wf[fh][ks][a] = *(const v8bf*)(u + woff[ks] + a * 2048);
+  };
+  auto barrier = []() { asm volatile("s_barrier" ::: "memory"); };
+#define G2_MFMA(FH, TH)                                                                                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                                         \
+  __builtin_amdgcn_s_setprio(1);                                                                             \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                              \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                              \
+    acc[2 * (FH) + a][4 * (TH) + b] =                                                                        \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[FH][ks][a], xf[ks][b], acc[2 * (FH) + a][4 * (TH) + b], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+
+  // ---- prologue: K tile 0 and three units of K tile 1 in flight, K tile 0 landed -----------------------------------
+#pragma unroll
+  for (int u = 0; u < kAhead2; ++u) issue(u);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+  if (wr == 1) barrier();   // waves 4-7 run one barrier (half a phase) behind their SIMD partners
+
+  for (int t = 0; t < nk; ++t) {
+    const uint8_t* buf = lds2 + (size_t)(t & 1) * kBuf2;
+    const int g = 4 * t;
+    // phase 0: quadrant (f0, t0)
+    read_w(buf, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(buf, 0);
+    issue(g + kAhead2);
+    barrier();
+    G2_MFMA(0, 0)
+    barrier();
+    // phase 1: quadrant (f1, t0)
+    read_w(buf, 1);
+    issue(g + 1 + kAhead2);
+    barrier();
+    G2_MFMA(1, 0)
+    barrier();
+    // phase 2: quadrant (f1, t1)
+    read_x(buf, 1);
+    issue(g + 2 + kAhead2);
+    barrier();
+    G2_MFMA(1, 1)
+    barrier();
+    // phase 3: quadrant (f0, t1); the one wait of the K tile: everything but the two youngest units has landed, i.e. all of
+    // K tile t + 1 (its first reads come two barriers later, behind every wave's wait)
+    issue(g + 3 + kAhead2);
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    G2_MFMA(0, 1)
+    barrier();
+  }
+  if (wr == 0) barrier();   // (same number of barriers in both halves)
+#undef G2_MFMA
+
+#ifdef VC_G2_PROBE_NOEPI   // timing probe: accumulators kept alive, nothing stored
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) asm volatile("" :: "v"(acc[a][b]));
+  asm volatile("s_barrier" ::: "memory");
+  continue;
+#endif
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------
+  // A lane holds, per (feature block a, token block b), 4 consecutive features of token 16 b + fr: 8 bytes of output.  Stored
+  // like that (32 stores of 8 bytes per lane) the epilogue cost 65 % of a K = 768 tile's main loop: the store path is bound by
+  // instructions, not bytes.  v_permlane16_swap pairs the feature blocks (a, a + 1): lanes of even fq take their neighbour's
+  // (l + 16) four features of block a, lanes of odd fq their neighbour's (l - 16) of block a + 1, so every lane owns 8
+  // consecutive features = ONE 16-byte store per block pair (16 per lane), and the residual comes in by the mirrored 16-byte
+  // load + the same swap (an involution).  Nothing is rounded before the residual add.
+  typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  typedef __bf16 v2bf16 __attribute__((ext_vector_type(2)));
+  const int odd = fq & 1;
+#pragma unroll
+  for (int ap = 0; ap < 2; ++ap) {           // feature block pairs (0,1), (2,3)
+    const int a0 = 2 * ap, a1 = a0 + 1;
+    const int nfeat = n0 + wc * 64 + (odd ? a1 * 16 + (fq - 1) * 4 : a0 * 16 + fq * 4);   // first of this lane's 8 features after the swap
+    const v4bf bv0 = *(const v4bf*)(bias + n0 + wc * 64 + a0 * 16 + fq * 4);
+    const v4bf bv1 = *(const v4bf*)(bias + n0 + wc * 64 + a1 * 16 + fq * 4);
+    // all residual loads of the pair first: interleaved with the stores, each load would wait for every older store
+    // (vmcnt counts both, in order) — 16 dependent round trips per lane
+    v4u32 r16s[8];
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        r16s[b] = *(const v4u32*)(res + (size_t)min(m0 + wr * 128 + b * 16 + fr, M - 1) * N + nfeat);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int m = m0 + wr * 128 + b * 16 + fr;
+      const size_t o = (size_t)min(m, M - 1) * N + nfeat;
+      float v0[4], v1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v0[j] = acc[a0][b][j] + (float)bv0[j]; v1[j] = acc[a1][b][j] + (float)bv1[j]; }
+      if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const v2f_t g0 = gelu_erf2((v2f_t){v0[j], v0[j + 1]}), g1 = gelu_erf2((v2f_t){v1[j], v1[j + 1]});
+          v0[j] = g0[0]; v0[j + 1] = g0[1]; v1[j] = g1[0]; v1[j + 1] = g1[1];
+        }
+      }
+      if (EPI == EPI_RESIDUAL) {
+        const v4u32 r16 = r16s[b];                      // (swapped layout) -> back to the accumulator layout
+        const auto rl = __builtin_amdgcn_permlane16_swap(r16[0], r16[2], false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(r16[1], r16[3], false, false);
+        const unsigned int w0[2] = {rl[0], rh[0]}, w1[2] = {rl[1], rh[1]};   // block a0's / a1's four residual features of this lane
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          v0[2 * j] += __uint_as_float(w0[j] << 16);
+          v0[2 * j + 1] += __uint_as_float(w0[j] & 0xffff0000u);
+          v1[2 * j] += __uint_as_float(w1[j] << 16);
+          v1[2 * j + 1] += __uint_as_float(w1[j] & 0xffff0000u);
+        }
+      }
+      unsigned int p0[2], p1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const v2bf16 q0 = {(__bf16)v0[2 * j], (__bf16)v0[2 * j + 1]}, q1 = {(__bf16)v1[2 * j], (__bf16)v1[2 * j + 1]};
+        p0[j] = *(const unsigned int*)&q0;
+        p1[j] = *(const unsigned int*)&q1;
+      }
+      const auto sl = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
+      const auto sh = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
+#if defined(VC_G2_PROBE_NOSTORE)       // timing probes (wrong output)
+      if (m < -1) *(v4u32*)(out + o) = (v4u32){sl[0], sh[0], sl[1], sh[1]};
+      asm volatile("" :: "v"(sl[0]), "v"(sh[0]), "v"(sl[1]), "v"(sh[1]));
+#elif defined(VC_G2_PROBE_COALSTORE)   // same bytes, each store instruction one contiguous KiB
+      { const size_t oc = (size_t)slot * 65536 + wave * 8192 + (ap * 8 + b) * 512 + lane * 8;
+        if (oc + 8 <= (size_t)M * N) *(v4u32*)(out + oc) = (v4u32){sl[0], sh[0], sl[1], sh[1]}; }
+#elif defined(VC_G2_PROBE_L2STORE)
+      if (m < M) *(v4u32*)(out + ((size_t)(m - m0 + (blockIdx.x & 31) * 256) * N + nfeat)) = (v4u32){sl[0], sh[0], sl[1], sh[1]};
+#else
+      if (m < M) *(v4u32*)(out + o) = (v4u32){sl[0], sh[0], sl[1], sh[1]};
+#endif
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");   // every wave is past its last fragment read of this tile before the next tile's copies land
+  }  // tiles of this workgroup
+}
+
+// =====================================================================================================
 // x-stationary kernel for K = 384 (every Linear of ViT-S that reads the 384-wide residual stream or the
 // attention output: qkv, proj, fc1).  The staged kernel above moves (128 + 128) x K bytes through
 // L2 -> LDS per 128 x 128 tile and is bound by that traffic (measured ~10 TB/s aggregate at 30 % MFMA
@@ -1439,14 +1699,47 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
   if ((((uintptr_t)x) | ((uintptr_t)weight) | ((uintptr_t)bias) | ((uintptr_t)residual_or_null) | ((uintptr_t)out)) % 16 != 0)
     return VC_ERR_INVALID_ARG;
   if (rows == 0) return VC_OK;
-  const int tiles_m = (rows + BM - 1) / BM, tiles_n = n_out / BN;
-  const long long nt = (long long)tiles_m * tiles_n;
-  if (nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)nt), block(256);
   hipStream_t s = (hipStream_t)stream;
   const __bf16 *px = (const __bf16*)x, *pw = (const __bf16*)weight, *pb = (const __bf16*)bias,
                *pr = (const __bf16*)residual_or_null;
   __bf16* po = (__bf16*)out;
+  static const int tile256 = [] { const char* e = getenv("VITCOLMAP_GEMM_TILE"); return e ? atoi(e) : 256; }();   // developer A/B: 128
+  if (n_out % G2N == 0 && rows >= 4 * G2M && tile256 == 256) {
+    // wide layers with enough rows to fill the chip: one 256 x 256 tile per workgroup, one workgroup per CU
+    const int tiles_m = (rows + G2M - 1) / G2M, tiles_n = n_out / G2N;
+    const long long nt = (long long)tiles_m * tiles_n;
+    if (nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+    const size_t smem = (size_t)G256_LDS;
+    static vc::PerDeviceOnce configured;
+    if (int st = configured.run([] {
+          hipError_t r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          return r;
+        }))
+      return st;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const dim3 grid((unsigned)(nt < cus ? nt : cus)), block(512);
+    switch (epilogue) {
+      case EPI_BIAS:
+        hipLaunchKernelGGL(gemm256_kernel<EPI_BIAS>, grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+        break;
+      case EPI_GELU:
+        hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+        break;
+      default:
+        hipLaunchKernelGGL(gemm256_kernel<EPI_RESIDUAL>, grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+        break;
+    }
+    return vc::check_launch();
+  }
+  const int tiles_m = (rows + BM - 1) / BM, tiles_n = n_out / BN;
+  const long long nt = (long long)tiles_m * tiles_n;
+  if (nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)nt), block(256);
   switch (epilogue) {
     case EPI_BIAS:
       hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 1);

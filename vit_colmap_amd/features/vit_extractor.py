@@ -459,7 +459,7 @@ class ViTExtractor(BaseExtractor):
             return img, time.perf_counter() - t0
 
         n_files = len(image_files)
-        workers = max(1, min(8, (os.cpu_count() or 2) - 1))
+        workers = max(1, min(16, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) - 1))
         ahead = 2 * self.batch_size
         with ThreadPoolExecutor(workers) as pool:
             futures = deque()
