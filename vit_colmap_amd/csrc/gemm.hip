@@ -390,77 +390,67 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
   continue;
 #endif
   // ---- epilogue ------------------------------------------------------------------------------------------------------------
-  // A lane holds, per (feature block a, token block b), 4 consecutive features of token 16 b + fr: 8 bytes of output.  Stored
-  // like that (32 stores of 8 bytes per lane) the epilogue cost 65 % of a K = 768 tile's main loop: the store path is bound by
-  // instructions, not bytes.  v_permlane16_swap pairs the feature blocks (a, a + 1): lanes of even fq take their neighbour's
-  // (l + 16) four features of block a, lanes of odd fq their neighbour's (l - 16) of block a + 1, so every lane owns 8
-  // consecutive features = ONE 16-byte store per block pair (16 per lane), and the residual comes in by the mirrored 16-byte
-  // load + the same swap (an involution).  Nothing is rounded before the residual add.
+  // A lane holds, per (feature block a, token block b), 4 consecutive features of token 16 b + fr: 8 bytes of an output row.
+  // Stored from that layout, a store instruction touches 16 to 64 rows with 8 to 16 bytes each, and the epilogue cost 40-65 %
+  // of a K = 768 tile's main loop (stores are bound by the lines they touch: same bytes in contiguous KiB ran 100 us per
+  // ViT-B layer faster).  Every wave therefore turns its 128 x 64 block through its own 16 KiB of the (now idle) staging
+  // buffers — all fragment reads of the tile are behind the last barrier: 8-byte writes from the accumulator layout, 16-byte
+  // reads of [8 rows][128 B] per instruction, so each store instruction writes 8 whole 128-byte lines.  The residual takes the
+  // same way in: whole-line loads, 16-byte LDS writes, and each lane picks up its own 8 bytes in the accumulator layout, adds
+  // in float32 and overwrites them with the rounded result (nothing is rounded before the residual add).  16-byte slots are
+  // XORed with (row >> 1) & 7: both views then spread over all banks (2 lanes per 8-byte bank pair, 4 per 16-byte group: the
+  // minimum for 512 / 1024 bytes per instruction).
   typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+  typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
   typedef __bf16 v2bf16 __attribute__((ext_vector_type(2)));
-  const int odd = fq & 1;
+  uint8_t* const ep = lds2 + (size_t)wave * 16384;
+  const int lrow = lane >> 3, lslot = lane & 7;          // whole-line view: row 8 i + lrow, 16-byte slot lslot
+  auto ep_at = [&](int row, int byte) { return ep + row * 128 + (byte ^ (((row >> 1) & 7) << 4)); };
+  const size_t col0 = (size_t)n0 + wc * 64;
+  if (EPI == EPI_RESIDUAL) {
+    v4u32 rr[16];
 #pragma unroll
-  for (int ap = 0; ap < 2; ++ap) {           // feature block pairs (0,1), (2,3)
-    const int a0 = 2 * ap, a1 = a0 + 1;
-    const int nfeat = n0 + wc * 64 + (odd ? a1 * 16 + (fq - 1) * 4 : a0 * 16 + fq * 4);   // first of this lane's 8 features after the swap
-    const v4bf bv0 = *(const v4bf*)(bias + n0 + wc * 64 + a0 * 16 + fq * 4);
-    const v4bf bv1 = *(const v4bf*)(bias + n0 + wc * 64 + a1 * 16 + fq * 4);
-    // all residual loads of the pair first: interleaved with the stores, each load would wait for every older store
-    // (vmcnt counts both, in order) — 16 dependent round trips per lane
-    v4u32 r16s[8];
-    if (EPI == EPI_RESIDUAL) {
+    for (int i = 0; i < 16; ++i)
+      rr[i] = *(const v4u32*)(res + (size_t)min(m0 + wr * 128 + 8 * i + lrow, M - 1) * N + col0 + lslot * 8);
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
-        r16s[b] = *(const v4u32*)(res + (size_t)min(m0 + wr * 128 + b * 16 + fr, M - 1) * N + nfeat);
-    }
+    for (int i = 0; i < 16; ++i) *(v4u32*)ep_at(8 * i + lrow, lslot * 16) = rr[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const v4bf bv = *(const v4bf*)(bias + col0 + a * 16 + fq * 4);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const int m = m0 + wr * 128 + b * 16 + fr;
-      const size_t o = (size_t)min(m, M - 1) * N + nfeat;
-      float v0[4], v1[4];
+      uint8_t* const pp = ep_at(16 * b + fr, 32 * a + 8 * fq);
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v0[j] = acc[a0][b][j] + (float)bv0[j]; v1[j] = acc[a1][b][j] + (float)bv1[j]; }
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] + (float)bv[j];
       if (EPI == EPI_GELU) {
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
-          const v2f_t g0 = gelu_erf2((v2f_t){v0[j], v0[j + 1]}), g1 = gelu_erf2((v2f_t){v1[j], v1[j + 1]});
-          v0[j] = g0[0]; v0[j + 1] = g0[1]; v1[j] = g1[0]; v1[j + 1] = g1[1];
+          const v2f_t g = gelu_erf2((v2f_t){v[j], v[j + 1]});
+          v[j] = g[0];
+          v[j + 1] = g[1];
         }
       }
       if (EPI == EPI_RESIDUAL) {
-        const v4u32 r16 = r16s[b];                      // (swapped layout) -> back to the accumulator layout
-        const auto rl = __builtin_amdgcn_permlane16_swap(r16[0], r16[2], false, false);
-        const auto rh = __builtin_amdgcn_permlane16_swap(r16[1], r16[3], false, false);
-        const unsigned int w0[2] = {rl[0], rh[0]}, w1[2] = {rl[1], rh[1]};   // block a0's / a1's four residual features of this lane
+        const v2u32 r8 = *(const v2u32*)pp;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          v0[2 * j] += __uint_as_float(w0[j] << 16);
-          v0[2 * j + 1] += __uint_as_float(w0[j] & 0xffff0000u);
-          v1[2 * j] += __uint_as_float(w1[j] << 16);
-          v1[2 * j + 1] += __uint_as_float(w1[j] & 0xffff0000u);
+          v[2 * j] += __uint_as_float(r8[j] << 16);
+          v[2 * j + 1] += __uint_as_float(r8[j] & 0xffff0000u);
         }
       }
-      unsigned int p0[2], p1[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const v2bf16 q0 = {(__bf16)v0[2 * j], (__bf16)v0[2 * j + 1]}, q1 = {(__bf16)v1[2 * j], (__bf16)v1[2 * j + 1]};
-        p0[j] = *(const unsigned int*)&q0;
-        p1[j] = *(const unsigned int*)&q1;
-      }
-      const auto sl = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
-      const auto sh = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
-#if defined(VC_G2_PROBE_NOSTORE)       // timing probes (wrong output)
-      if (m < -1) *(v4u32*)(out + o) = (v4u32){sl[0], sh[0], sl[1], sh[1]};
-      asm volatile("" :: "v"(sl[0]), "v"(sh[0]), "v"(sl[1]), "v"(sh[1]));
-#elif defined(VC_G2_PROBE_COALSTORE)   // same bytes, each store instruction one contiguous KiB
-      { const size_t oc = (size_t)slot * 65536 + wave * 8192 + (ap * 8 + b) * 512 + lane * 8;
-        if (oc + 8 <= (size_t)M * N) *(v4u32*)(out + oc) = (v4u32){sl[0], sh[0], sl[1], sh[1]}; }
-#elif defined(VC_G2_PROBE_L2STORE)
-      if (m < M) *(v4u32*)(out + ((size_t)(m - m0 + (blockIdx.x & 31) * 256) * N + nfeat)) = (v4u32){sl[0], sh[0], sl[1], sh[1]};
-#else
-      if (m < M) *(v4u32*)(out + o) = (v4u32){sl[0], sh[0], sl[1], sh[1]};
-#endif
+      const v2bf16 q0 = {(__bf16)v[0], (__bf16)v[1]}, q1 = {(__bf16)v[2], (__bf16)v[3]};
+      *(v2u32*)pp = (v2u32){*(const unsigned int*)&q0, *(const unsigned int*)&q1};
     }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = 8 * i + lrow, m = m0 + wr * 128 + row;
+    const v4u32 o = *(const v4u32*)ep_at(row, lslot * 16);
+    if (m < M) *(v4u32*)(out + (size_t)m * N + col0 + lslot * 8) = o;
   }
   asm volatile("s_barrier" ::: "memory");   // every wave is past its last fragment read of this tile before the next tile's copies land
   }  // tiles of this workgroup
