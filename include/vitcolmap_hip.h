@@ -276,6 +276,9 @@ int vc_attention_bf16(const void* qkv, int batch, int n_tokens, int n_heads, int
  * The pre-activation is NOT rounded to bf16 before GELU / the residual add (one rounding less than
  * the unfused sequence).  n_out % 128 == 0, k_in % 64 == 0, pointers 16-byte aligned,
  * residual_or_null non-NULL exactly for VC_EPI_RESIDUAL.
+ * Two tile forms behind the one entry: a 256 x 256 persistent tile (one workgroup per CU, 128 KiB staging ring) when
+ * n_out % 256 == 0 and rows >= 1024 — the ViT-B / ViT-L layers — and a 128 x 128 tile otherwise; same arithmetic, the
+ * accumulation order over k_in is the same in both.
  * Replaces the nn.Linear / GELU / residual-add calls inside the hub model's blocks
  * (reference vit_extractor.py:135-146).
  */
