@@ -127,11 +127,12 @@ def test_linear_rejects_unsupported_shapes():
 
 
 @pytest.mark.parametrize("rows,N", [(1531 * 2, 1152), (300, 384), (1531 * 3, 1536), (1, 32), (255, 64), (257, 96),
-                                    (256 * 300, 384)])
+                                    (256 * 300, 384), (1531 * 50, 1152), (1531 * 50 + 37, 384)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("ln", [False, True])
 def test_xs_linear_matches_float32_reference(rows, N, epi, ln):
-    """x-stationary K=384 GEMM (+ fused LayerNorm / epilogue) through the C ABI vs float32 on the same bf16 data."""
+    """K=384 GEMM (+ fused LayerNorm / epilogue) through the C ABI vs float32 on the same bf16 data: the x-stationary kernel
+    and, for the long launches without LayerNorm (the last three shapes), the weight-stationary one behind the same entry."""
     from vit_colmap_amd.vit.hip_ops import XsLinear
 
     K = 384
