@@ -289,6 +289,22 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
                    void* out, int rows, int n_out, int k_in, int epilogue, vc_stream_t stream);
 
 /*
+ * Convolution over a channels-last image batch as an implicit GEMM on the 256 x 256 tile (the convolutional heads of the
+ * trainable extractor: reference vit_colmap/model/vit_feature_model.py:12-29 UpsampleBlock — ConvTranspose2d(4, stride 2,
+ * pad 1) as four 2 x 2-tap products, one per output parity — and :96-120 trunk / heads, Conv2d 3 x 3 pad 1; eval-mode
+ * BatchNorm folded into weight and bias by the caller):
+ *   out[(b, y, x)][n] = epi( sum over taps t = (ty, tx), channels c of
+ *                            x[b][y + dy0 + ty][x + dx0 + tx][c] * weight[n][(ty * kw + tx) * c_in + c]  + bias[n] ),
+ * pixels outside the image contribute zero.  x [batch * height * width + 1][c_in] bf16: the image batch followed by ONE spare
+ * row, which this call overwrites with zeros (taps outside the image read it); weight [n_out][kh * kw * c_in] bf16, bias
+ * [n_out] bf16, out [batch * height * width][n_out] bf16.  epilogue VC_EPI_BIAS or VC_EPI_GELU.  n_out % 256 == 0,
+ * c_in % 64 == 0, kh * kw <= 16, the batch below 4 GiB, 16-byte aligned pointers.  A 3 x 3 pad-1 convolution is
+ * (kh, kw, dy0, dx0) = (3, 3, -1, -1).
+ */
+int vc_conv_taps_bf16(void* x, const void* weight, const void* bias, void* out, int batch, int height, int width, int c_in,
+                      int n_out, int kh, int kw, int dy0, int dx0, int epilogue, vc_stream_t stream);
+
+/*
  * The same linear layer for k_in == 384 (ViT-S: attn.qkv, attn.proj, mlp.fc1), "x-stationary":
  * each wave keeps its 32 token rows in registers for the whole launch and only the weights stream
  * (csrc/gemm.hip).  Optionally fuses the LayerNorm that precedes the layer in a pre-norm block:

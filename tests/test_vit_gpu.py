@@ -167,6 +167,38 @@ def test_xs_linear_matches_float32_reference(rows, N, epi, ln):
         assert torch.equal(r2.float(), out)
 
 
+@pytest.mark.parametrize("B,H,W,C,N,kh,kw,dy0,dx0,epi", [
+    (2, 34, 45, 384, 256, 3, 3, -1, -1, 0),      # 3 x 3 pad 1 on the token grid
+    (1, 68, 90, 512, 512, 3, 3, -1, -1, 1),      # the upsampler's conv + GELU
+    (3, 17, 23, 128, 256, 2, 2, -1, -1, 0),      # one parity class of the transposed convolution (taps up / left)
+    (3, 17, 23, 128, 256, 2, 2, 0, 0, 1),        # ... (taps down / right)
+    (1, 5, 7, 64, 256, 1, 1, 0, 0, 0),           # 1 x 1: a plain GEMM, fewer rows than one tile
+    (2, 120, 160, 256, 256, 3, 3, -1, -1, 1)])   # the heads' resolution
+def test_conv_taps_matches_float32_convolution(B, H, W, C, N, kh, kw, dy0, dx0, epi):
+    """vc_conv_taps_bf16 (implicit GEMM over a channels-last batch, zero outside the image) vs torch's float32 conv2d on the
+    same bf16 data; the spare row behind the batch is filled with junk first (the call must zero it)."""
+    from vit_colmap_amd.vit.hip_ops import conv_rows, conv_taps
+
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H + C + kh + epi)
+    xr = conv_rows(B, H, W, C, "cuda")
+    xr.copy_((torch.randn(xr.shape, device="cuda", generator=g) * 1.2 + 0.2).to(torch.bfloat16))   # spare row: junk
+    k = kh * kw * C
+    w = (torch.randn(N, kh, kw, C, device="cuda", generator=g) / k ** 0.5 * torch.linspace(0.5, 2, N, device="cuda")[:, None, None, None]).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    out = conv_taps(xr, w.reshape(N, k).contiguous(), b, B, H, W, kh, kw, dy0, dx0, epi).float()
+    assert not bool(xr[B * H * W].any())
+    img = xr[: B * H * W].float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    # out(y, x) = sum_t in(y + dy0 + ty, x + dx0 + tx) w[t]  ==  cross-correlation with padding (top = -dy0, left = -dx0, ...)
+    pad = (-dx0, kw - 1 + dx0, -dy0, kh - 1 + dy0)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(img, pad), w.float().permute(0, 3, 1, 2), b.float())
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, N)
+    err = (out - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -7 + 2e-2).all()), (float(err.max()), int((err > ref.abs() * 2 ** -7 + 2e-2).sum()))
+    assert float((out - ref).norm() / ref.norm()) < 4e-3
+
+
 def test_patch_embed_gemm_matches_reference_and_padded_preprocess():
     """vc_patch_embed_bf16 (patch embedding + bias + position embedding, class-token row skipped) vs float32 on the
     same bf16 data, and the padded patch layout of the preprocessing kernel vs the unpadded one."""

@@ -233,11 +233,16 @@ constexpr int kBuf2 = 4 * kUnit2;         // X0 | W0 | W1 | X1
 constexpr int G256_LDS = 2 * kBuf2;       // 128 KiB
 constexpr int kAhead2 = 6;                // units issued ahead of the phase that runs
 
-template <int EPI>
+// CONV: the same kernel as an implicit GEMM over a channels-last image batch x [batch][cH][cW][cC] (+ one trailing row of cC
+// zeros, row M): output row m = (b, y, x) gathers kh x ckw taps, K = taps * cC, k = (tap, channel); tap t reads the row of
+// pixel (y + cdy0 + t / ckw, x + cdx0 + t % ckw) of the same image, or the zero row when that pixel is outside it.  A K tile
+// (64 channels of one tap) is the same 1 KiB pieces as before — the tap only moves the scalar base, and a lane whose pixel
+// is outside points at the zero row instead (one v_cndmask per piece).  W [N][K] with k in the same (tap, channel) order.
+template <int EPI, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W,
                                                          const __bf16* __restrict__ bias, const __bf16* __restrict__ res,
                                                          __bf16* __restrict__ out, int M, int N, int K, int n_tiles_n,
-                                                         int n_tiles) {
+                                                         int n_tiles, int cH, int cW, int cC, int ckw, int cdy0, int cdx0) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds2[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,27 +267,51 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)&lds2[0]);
   const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
   uint32_t voffx[2][2], voffw[2];          // per-lane byte offsets from X / W (+ k offset of the K tile added as a scalar)
+  uint32_t vtaps[2][2];                    // CONV: bit t set = tap t of this lane's pixel lies inside the image
+  const int n_taps = CONV ? K / cC : 1, tiles_per_tap = CONV ? cC / BK : 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rho = (wave * 2 + i) * 8 + prow;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int xr = (rho < 64 ? rho : 128 + (rho - 64)) + 64 * h;
-      voffx[h][i] = (uint32_t)(((size_t)min(m0 + xr, M - 1) * K + pchunk * 8) * 2 - (size_t)min(m0, M - 1) * K * 2);
+      if (CONV) {
+        const int m = m0 + xr, hw = cH * cW;
+        const int bimg = m / hw, rem = m - bimg * hw, py = rem / cW, px = rem - py * cW;
+        uint32_t bits = 0;
+        for (int t = 0; t < n_taps; ++t) {
+          const int yy = py + cdy0 + t / ckw, xx = px + cdx0 + t % ckw;
+          if (m < M && yy >= 0 && yy < cH && xx >= 0 && xx < cW) bits |= 1u << t;
+        }
+        vtaps[h][i] = bits;
+        voffx[h][i] = (uint32_t)(((size_t)min(m, M - 1) * cC + pchunk * 8) * 2);
+      } else {
+        voffx[h][i] = (uint32_t)(((size_t)min(m0 + xr, M - 1) * K + pchunk * 8) * 2 - (size_t)min(m0, M - 1) * K * 2);
+      }
     }
     const int wrow = (rho >> 5) * 64 + (rho & 31);
     voffw[i] = (uint32_t)(((size_t)wrow * K + pchunk * 8) * 2);
   }
-  const char* const xbase = (const char*)(X + (size_t)min(m0, M - 1) * K);
+  const char* const xbase = CONV ? (const char*)X : (const char*)(X + (size_t)min(m0, M - 1) * K);
   const char* const wbase = (const char*)(W + (size_t)n0 * K);
   const size_t whalf = (size_t)32 * K * 2;
   auto issue = [&](int u) {
     if (u >= n_units) return;
     const int t = u >> 2, j = u & 3;
-    const char* sb = (j == 0 || j == 3) ? xbase + (size_t)t * (BK * 2) : wbase + (size_t)t * (BK * 2) + (j == 2 ? whalf : 0);
+    const bool is_x = j == 0 || j == 3;
+    const char* sb = is_x ? xbase + (size_t)t * (BK * 2) : wbase + (size_t)t * (BK * 2) + (j == 2 ? whalf : 0);
+    int tap = 0;
+    uint32_t zoff = 0;                     // CONV: offset (from sb) of this lane's 16 bytes in the zero row
+    if (CONV && is_x) {
+      tap = t / tiles_per_tap;
+      const long long shift = ((long long)(cdy0 + tap / ckw) * cW + (cdx0 + tap % ckw)) * cC * 2;   // bytes, may be negative
+      sb = xbase + shift + (long long)(t - tap * tiles_per_tap) * (BK * 2);
+      zoff = (uint32_t)((long long)M * cC * 2 - shift) + (uint32_t)pchunk * 16u;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const uint32_t vo = j == 0 ? voffx[0][i] : (j == 3 ? voffx[1][i] : voffw[i]);
+      uint32_t vo = j == 0 ? voffx[0][i] : (j == 3 ? voffx[1][i] : voffw[i]);
+      if (CONV && is_x) vo = ((j == 0 ? vtaps[0][i] : vtaps[1][i]) >> tap) & 1u ? vo : zoff;
       const uint32_t dst = lds0 + (uint32_t)(t & 1) * kBuf2 + (uint32_t)j * kUnit2 + (uint32_t)(wave * 2 + i) * 1024u;
       uint32_t keep;
       asm volatile(
@@ -1703,9 +1732,9 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
     const size_t smem = (size_t)G256_LDS;
     static vc::PerDeviceOnce configured;
     if (int st = configured.run([] {
-          hipError_t r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipError_t r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RESIDUAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           return r;
         }))
       return st;
@@ -1716,13 +1745,13 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
     const dim3 grid((unsigned)(nt < cus ? nt : cus)), block(512);
     switch (epilogue) {
       case EPI_BIAS:
-        hipLaunchKernelGGL(gemm256_kernel<EPI_BIAS>, grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+        hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0);
         break;
       case EPI_GELU:
-        hipLaunchKernelGGL(gemm256_kernel<EPI_GELU>, grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+        hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0);
         break;
       default:
-        hipLaunchKernelGGL(gemm256_kernel<EPI_RESIDUAL>, grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt);
+        hipLaunchKernelGGL((gemm256_kernel<EPI_RESIDUAL, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0);
         break;
     }
     return vc::check_launch();
@@ -1742,6 +1771,46 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
       hipLaunchKernelGGL(gemm_kernel<EPI_RESIDUAL>, grid, block, 0, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 1);
       break;
   }
+  return vc::check_launch();
+}
+
+
+int vc_conv_taps_bf16(void* x, const void* weight, const void* bias, void* out, int batch, int height, int width, int c_in,
+                      int n_out, int kh, int kw, int dy0, int dx0, int epilogue, vc_stream_t stream) {
+  if (!x || !weight || !bias || !out || batch < 0 || height <= 0 || width <= 0 || c_in <= 0 || n_out <= 0) return VC_ERR_INVALID_ARG;
+  if (epilogue != EPI_BIAS && epilogue != EPI_GELU) return VC_ERR_INVALID_ARG;
+  if (kh <= 0 || kw <= 0 || kh * kw > 16 || dy0 < -8 || dy0 > 8 || dx0 < -8 || dx0 > 8) return VC_ERR_INVALID_ARG;
+  if (n_out % G2N != 0 || c_in % BK != 0) return VC_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)weight) | ((uintptr_t)bias) | ((uintptr_t)out)) % 16 != 0) return VC_ERR_INVALID_ARG;
+  const long long rows = (long long)batch * height * width;
+  if (rows == 0) return VC_OK;
+  // per-lane offsets are 32-bit: the image batch, its zero row and the largest tap shift must stay below 4 GiB
+  if ((rows + 1 + (long long)(kh + 8) * width) * c_in * 2 >= (1LL << 32) || rows > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync((char*)x + (size_t)rows * c_in * 2, 0, (size_t)c_in * 2, s) != hipSuccess) return vc::fail(hipGetLastError());
+  const int k_total = kh * kw * c_in;
+  const int tiles_m = (int)((rows + G2M - 1) / G2M), tiles_n = n_out / G2N;
+  const long long nt = (long long)tiles_m * tiles_n;
+  if (nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  static vc::PerDeviceOnce configured;
+  if (int st = configured.run([] {
+        hipError_t r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (r == hipSuccess) r = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return r;
+      }))
+    return st;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  const dim3 grid((unsigned)(nt < cus ? nt : cus)), block(512);
+  const __bf16 *px = (const __bf16*)x, *pw = (const __bf16*)weight, *pb = (const __bf16*)bias;
+  __bf16* po = (__bf16*)out;
+  if (epilogue == EPI_BIAS)
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, true>), grid, block, (size_t)G256_LDS, s, px, pw, pb, (const __bf16*)nullptr, po, (int)rows,
+                       n_out, k_total, tiles_n, (int)nt, height, width, c_in, kw, dy0, dx0);
+  else
+    hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, true>), grid, block, (size_t)G256_LDS, s, px, pw, pb, (const __bf16*)nullptr, po, (int)rows,
+                       n_out, k_total, tiles_n, (int)nt, height, width, c_in, kw, dy0, dx0);
   return vc::check_launch();
 }
 

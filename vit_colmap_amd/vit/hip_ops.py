@@ -76,6 +76,32 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, epilogue: 
     return out
 
 
+def conv_rows(batch: int, height: int, width: int, channels: int, device) -> torch.Tensor:
+    """A channels-last activation buffer for `conv_taps`: [batch * height * width + 1][channels] bf16 — the image batch plus
+    the spare row the kernel keeps at zero for taps outside the image."""
+    return torch.empty((batch * height * width + 1, channels), dtype=torch.bfloat16, device=device)
+
+
+def conv_taps(x_rows: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, batch: int, height: int, width: int,
+              kh: int, kw: int, dy0: int, dx0: int, epilogue: int = EPI_BIAS, out=None) -> torch.Tensor:
+    """Convolution over a channels-last image batch on the 256 x 256 implicit-GEMM tile (vc_conv_taps_bf16):
+    x_rows [batch * height * width + 1][c_in] (see conv_rows), weight [n_out][kh * kw * c_in] with k = (tap, channel),
+    out [batch * height * width (+ anything)][n_out].  A 3 x 3 pad-1 convolution is (kh, kw, dy0, dx0) = (3, 3, -1, -1)."""
+    rows = batch * height * width
+    c_in = x_rows.shape[1]
+    n = weight.shape[0]
+    assert x_rows.is_cuda and x_rows.dtype == torch.bfloat16 and x_rows.is_contiguous() and x_rows.shape[0] >= rows + 1
+    assert weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] == kh * kw * c_in
+    assert bias.dtype == torch.bfloat16 and bias.numel() == n
+    if out is None:
+        out = torch.empty((rows, n), dtype=torch.bfloat16, device=x_rows.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[-1] == n and out.numel() >= rows * n
+    lib = _lib.load()
+    _lib.check(lib.vc_conv_taps_bf16(_lib.ptr(x_rows), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), batch, height, width,
+                                     c_in, n, kh, kw, dy0, dx0, epilogue, _lib.stream_ptr()), "vc_conv_taps_bf16")
+    return out
+
+
 class XsLinear:
     """A Linear with k_in == 384 prepared for csrc/gemm.hip's x-stationary kernel (optionally with the
     preceding LayerNorm folded in).  Built once from float32 parameters; call with bf16 activations."""
