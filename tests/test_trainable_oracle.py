@@ -96,3 +96,43 @@ def test_fold_batchnorm_is_exact_up_to_rounding():
     assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in m.modules())
     for k in ("keypoints", "descriptors"):
         np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-5)
+
+
+def _tap_product(x_nhwc, mat, bias, kh, kw, dy0, dx0):
+    """float32 restatement of vc_conv_taps_bf16's definition (include/vitcolmap_hip.h): out[b, y, x, n] = sum over taps
+    (ty, tx) and channels of x[b, y + dy0 + ty, x + dx0 + tx, c] * mat[n, (ty * kw + tx) * C + c] + bias[n], zero outside."""
+    import torch
+
+    B, H, W, C = x_nhwc.shape
+    out = bias.reshape(1, 1, 1, -1).expand(B, H, W, mat.shape[0]).clone()
+    for ty in range(kh):
+        for tx in range(kw):
+            dy, dx = dy0 + ty, dx0 + tx
+            shifted = torch.zeros_like(x_nhwc)
+            ys, ye = max(0, -dy), min(H, H - dy)
+            xs, xe = max(0, -dx), min(W, W - dx)
+            shifted[:, ys:ye, xs:xe] = x_nhwc[:, ys + dy:ye + dy, xs + dx:xe + dx]
+            t = ty * kw + tx
+            out = out + shifted @ mat[:, t * C:(t + 1) * C].t()
+    return out
+
+
+def test_hip_heads_weight_layouts_reproduce_conv_and_transposed_conv():
+    """model/hip_heads.py: the (tap, channel) matrices handed to vc_conv_taps_bf16 — 3 x 3 convolution and the four parity
+    classes of ConvTranspose2d(4, stride 2, pad 1) — evaluated with the entry's definition in float32 equal torch's layers."""
+    import torch
+
+    from vit_colmap_amd.model.hip_heads import conv3x3_matrix, deconv_class_matrices
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 7, 6, generator=g, dtype=torch.float64)                       # NHWC
+    conv = torch.nn.Conv2d(6, 4, 3, padding=1).double()
+    ref = conv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    got = _tap_product(x, conv3x3_matrix(conv.weight), conv.bias.detach(), 3, 3, -1, -1)
+    assert torch.allclose(got, ref, atol=1e-12)
+    dec = torch.nn.ConvTranspose2d(6, 4, kernel_size=4, stride=2, padding=1).double()
+    ref = dec(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)                                  # (2, 10, 14, 4)
+    got = torch.zeros_like(ref)
+    for mat, i, j, dy0, dx0 in deconv_class_matrices(dec.weight):
+        got[:, i::2, j::2] = _tap_product(x, mat, dec.bias.detach(), 2, 2, dy0, dx0)
+    assert torch.allclose(got, ref, atol=1e-12)

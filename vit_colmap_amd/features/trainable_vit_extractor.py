@@ -93,6 +93,8 @@ class TrainableViTExtractor(BaseExtractor):
             self.model.trunk.to(memory_format=torch.channels_last)
             self.model.keypoint_head.to(memory_format=torch.channels_last)
             self.model.descriptor_head.to(memory_format=torch.channels_last)
+            if self.dtype == torch.bfloat16:
+                self.model.prepare_hip_heads()         # upsampler / trunk / heads on vc_conv_taps_bf16 instead of MIOpen
         self.patch_size = self.model.patch_size
         counts = self.model.count_parameters()
         print("✓ Model loaded successfully")

@@ -2,10 +2,11 @@
 reference's `vit_colmap/model/vit_feature_model.py:12-293` (same submodule names, so a trained reference state dict
 loads: `backbone.*`, `upsampler.{0,1}.{deconv,conv,bn}`, `trunk.{0,1}`, `keypoint_head.{0,1,3}`, `descriptor_head.{0,1,3}`).
 
-What runs where: the backbone is this package's DINOv2 (`vit/dinov2.py`: hand-written kernels for ViT-S, PyTorch-ROCm
-GEMMs + the HIP attention kernel for ViT-B/L); the convolutional heads are PyTorch-ROCm (MIOpen) modules — plumbing —
-kept channels-last so the token grid (B, Hp*Wp, C) of the backbone IS their input without a transpose; what follows the
-model (sigmoid, NMS, top-k, sub-pixel keypoints, descriptor quantiser) is csrc/heatmap.hip.
+What runs where: the backbone is this package's DINOv2 (`vit/dinov2.py`: hand-written kernels for ViT-S / B / L); the
+convolutional heads run, in the bf16 product path, on the hand-written implicit-GEMM convolution (`model/hip_heads.py`,
+`vc_conv_taps_bf16`; round 3) — channels-last, so the token grid (B, Hp*Wp, C) of the backbone IS their input without a
+transpose — and as PyTorch-ROCm (MIOpen) modules in float32 / on request; what follows the model (sigmoid, NMS, top-k,
+sub-pixel keypoints, descriptor quantiser) is csrc/heatmap.hip.
 
 Differences from the reference, deliberate: the backbone comes from `build_dinov2` (torch.hub is unreachable offline)
 with seeded random weights unless a state dict is loaded; training-only members (`get_trainable_parameters`,
@@ -95,6 +96,11 @@ class ViTFeatureModel(nn.Module):
         """vit_feature_model.py:231-293: upsample x4, bilinear resize to the 1/4-resolution target, trunk, heads,
         orientation = tanh * pi, descriptors L2-normalised over channels."""
         head_dtype = self.trunk[0].weight.dtype
+        heads = getattr(self, "_hip_heads", None)
+        if heads is not None and backbone_features.is_cuda and head_dtype == torch.bfloat16:
+            B, C, hp, wp = backbone_features.shape
+            tokens = backbone_features.permute(0, 2, 3, 1).reshape(B, hp * wp, C).to(torch.bfloat16)   # a view for a channels-last grid
+            return heads(tokens.contiguous(), hp, wp, target_size)
         up = self.upsampler(backbone_features.to(head_dtype))
         if target_size is None:
             hp, wp = backbone_features.shape[2:]
@@ -124,6 +130,16 @@ class ViTFeatureModel(nn.Module):
         for seq in (self.trunk, self.keypoint_head, self.descriptor_head):
             fold(seq[0], seq[1])
             seq[1] = nn.Identity()
+        return self
+
+    def prepare_hip_heads(self):
+        """After fold_batchnorm() and the cast to bf16 on the GPU: run upsampler, trunk and heads on the hand-written
+        implicit-GEMM convolution (model/hip_heads.py) instead of MIOpen.  `VITCOLMAP_HIP_HEADS=0` keeps the library path."""
+        import os
+
+        from .hip_heads import HipHeads
+
+        self._hip_heads = HipHeads(self) if os.environ.get("VITCOLMAP_HIP_HEADS", "1") != "0" else None
         return self
 
     # ------------------------------------------------------------------------------------------
