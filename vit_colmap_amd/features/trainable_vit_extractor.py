@@ -60,7 +60,7 @@ class TrainableViTExtractor(BaseExtractor):
         nms_radius: int = 4,
         *,
         precision: str = "bf16",     # "bf16": backbone and convolutional heads on the matrix cores; "fp32": the reference's precision
-        batch_size: int = 8,
+        batch_size: int = 32,        # images per device batch (4-6 GiB of head activations at 640 x 480; 8 leaves the backbone's persistent kernels half empty)
         seed: int = 0,
     ):
         self.weights_path = weights_path
