@@ -26,12 +26,12 @@ for r in rows:
             per_layer[lab] = float(r["AverageNs"]) / 1e3
 md = f"""# rocprofv3 --kernel-trace --stats — `python bench.py --no-cpu-baseline --no-strong-anchor` (round 3, 1x MI355X)
 
-155 end-to-end steps (5 warm-up + 150 timed, 50 images each, the ViT block loop as two batch shards on two HIP streams), then the
+155 end-to-end steps (5 warm-up + 150 timed, 50 images each; consecutive steps are pipelined, whole batches alternating between two HIP streams), then the
 matcher loops of the same process on 512 x 384 blocks (3 warm-up + 1 probe + {d['roofline']['launches_timed']} timed launches on the configs[2] input —
 `roofline` — and the same on the dense input — `roofline_dense`) and the two short 2048 x 256 legs (`matcher_c5_shape`,
 `pair2_kernel<8>`).  Raw per-kernel table: `r03_bench_kernel_stats.csv`; the JSON line the profiled run printed:
-`r03_bench_line_profiled.json` (tracing slows the 150 steps by a few percent: {d['ms_per_step']} ms per step here; with kernels of the two
-shards overlapping, a kernel's traced duration includes the time it shares the chip with the other shard's kernel, so the per-layer
+`r03_bench_line_profiled.json` (tracing slows the 150 steps by a few percent: {d['ms_per_step']} ms per step here; with kernels of two
+batches overlapping, a kernel's traced duration includes the time it shares the chip with the other batch's kernels, so the per-layer
 averages below are longer than the single-stream figures of round 2 although the step is shorter).  Collected by `tools/prof_r03.sh`,
 summarised by `tools/write_profiles_r03.py`.
 
