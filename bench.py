@@ -428,6 +428,34 @@ def main():
             sys.stdout = so
             shutil.rmtree(tmp, ignore_errors=True)
 
+    # ---- the other extractor of the plugin API, device-resident like `value`: informational ----------
+    trainable = None
+    if world == 1 and args.config == "c2" and rank == 0 and not args.no_strong_anchor:
+        from vit_colmap_amd.features.trainable_vit_extractor import TrainableViTExtractor
+
+        sys.stdout = quiet
+        try:
+            tex = TrainableViTExtractor(model_name="dinov2_vits14", num_keypoints=2048, device=f"cuda:{local_rank}")
+            tb = 32
+            tframes = torch.from_numpy(synthetic_frames(0, tb)).to(dev)
+            for _ in range(2):
+                tex.extract_device(tframes)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                tex.extract_device(tframes)
+            torch.cuda.synchronize()
+            tdt = (time.perf_counter() - t0) / 5
+            trainable = {
+                "value": round(tb / tdt, 1), "unit": "images/s", "batch": tb, "ms_per_batch": round(tdt * 1e3, 3),
+                "what": "TrainableViTExtractor(dinov2_vits14, 2048 keypoints).extract_device on 640x480 frames resident in HBM: "
+                        "ViT-S backbone + convolutional heads (vc_conv_taps_bf16: implicit GEMM on the 256x256 tile, 265 GFLOP per "
+                        "image) + heat-map selection; random weights; NOT part of `value`",
+            }
+            del tex, tframes
+        finally:
+            sys.stdout = so
+
     if rank == 0:
         bpp, opp = cfg["bytes_per_pair"], cfg["ops_per_pair"]
         achieved = P * bpp / (launch_ms * 1e-3) / 1e9          # rank 0's launch, rank 0's GPU
@@ -516,6 +544,7 @@ def main():
             "matcher_c5_shape": c5_shape,
             "strong_scaling_200": strong_anchor,
             "extract_e2e_images_per_s": e2e,
+            "trainable_extractor_images_per_s": trainable,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline(frames_np)

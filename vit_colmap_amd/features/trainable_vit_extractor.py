@@ -232,15 +232,42 @@ class TrainableViTExtractor(BaseExtractor):
                 db.add_descriptors(image_id, descriptors)
             pending.clear()
 
-        for idx, img_file in enumerate(image_files, start=1):
-            img = first_img if idx == 1 else image_io.imread(img_file)
-            if img is None:
-                print(f"[{idx}/{len(image_files)}] {img_file.name}: Warning: Failed to read image, skipping")
-                continue
-            image_id = db.add_image(img_file.name, camera_id=camera_id)      # before inference (:358)
-            if pending and (pending[0][2].shape != img.shape or len(pending) >= self.batch_size):
-                flush()
-            pending.append((image_id, img_file.name, img))
-        flush()
+        # files are decoded ahead of the loop by a thread pool (the reference's loop is serial: imread -> inference -> write,
+        # :340-390); results are consumed in file order, so image ids are those of the serial loop
+        import os
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        workers = max(1, min(16, len(os.sched_getaffinity(0)) - 1 if hasattr(os, "sched_getaffinity") else 4))
+        window = max(2 * self.batch_size, 2 * workers)
+        pool = ThreadPoolExecutor(max_workers=workers)
+        ahead = deque()
+        files_iter = iter(image_files[1:])
+
+        def refill():
+            while len(ahead) < window:
+                f = next(files_iter, None)
+                if f is None:
+                    return
+                ahead.append(pool.submit(image_io.imread, f))
+
+        try:
+            refill()
+            for idx, img_file in enumerate(image_files, start=1):
+                if idx == 1:
+                    img = first_img
+                else:
+                    img = ahead.popleft().result()
+                    refill()
+                if img is None:
+                    print(f"[{idx}/{len(image_files)}] {img_file.name}: Warning: Failed to read image, skipping")
+                    continue
+                image_id = db.add_image(img_file.name, camera_id=camera_id)      # before inference (:358)
+                if pending and (pending[0][2].shape != img.shape or len(pending) >= self.batch_size):
+                    flush()
+                pending.append((image_id, img_file.name, img))
+            flush()
+        finally:
+            pool.shutdown(wait=False, cancel_futures=True)
         db.commit()
         print(f"\n{'='*60}\nFeature extraction complete!\n{'='*60}\n")
