@@ -1310,6 +1310,9 @@ static_assert(M2Lds <= 160 * 1024, "fused MLP: LDS budget");
 #ifndef VC_MLP_RD
 #define VC_MLP_RD 6          // weight fragments read ahead of the MFMA that uses them
 #endif
+#ifndef VC_MLP_NA
+#define VC_MLP_NA 3           // LDS-DMA pieces of a stage issued by each fc1 wave (each fc2 wave issues 12 - NA): the fc1 role is the longer one
+#endif
 #ifndef VC_MLP_ISSUE0
 #define VC_MLP_ISSUE0 1       // first MFMA behind which a piece of the next stage is issued ...
 #define VC_MLP_ISSUE_STEP 3   // ... and the distance to the next one (sweep: 1+3k 228 us, 1+2k 229, 0+k 233, 1+4k 235)
@@ -1342,11 +1345,15 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
   // shared by all pieces — with a 64-bit address per piece in VGPRs the compiler kept six pairs alive, spilled them,
   // and every reload in the stage loop waited for vmcnt(0), i.e. for the copy just issued
   const uint32_t lane_off = (uint32_t)lane * 16u;
+  constexpr int NA = VC_MLP_NA, NB = 12 - NA;       // pieces per fc1 / fc2 wave and stage (48 pieces: 24 of W1, then 24 of W2)
   auto issue_piece = [&](int c1, int c2, int slot, int i) {
-    const int half = wave >> 2, q = wave & 3;
+    const int role = wave >> 2, q = wave & 3;
+    if (i >= (role ? NB : NA)) return;
+    const int id = role ? 4 * NA + q * NB + i : q * NA + i;
+    const int half = id >= 24, idx = id - 24 * half;
     const int c = half ? c2 : c1;
-    const uint8_t* sbase = Wm + (size_t)c * MStage + (size_t)half * XStage + (size_t)(q * 6 + i) * 1024;
-    const uint32_t dst = lds0 + (uint32_t)slot * MStage + (uint32_t)half * XStage + (uint32_t)(q * 6 + i) * 1024u;
+    const uint8_t* sbase = Wm + (size_t)c * MStage + (size_t)half * XStage + (size_t)idx * 1024;
+    const uint32_t dst = lds0 + (uint32_t)slot * MStage + (uint32_t)half * XStage + (uint32_t)idx * 1024u;
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -1360,7 +1367,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
   };
   auto issue = [&](int c1, int c2, int slot) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_piece(c1, c2, slot, i);
+    for (int i = 0; i < (NA > NB ? NA : NB); ++i) issue_piece(c1, c2, slot, i);
   };
   typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1528,7 +1535,7 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
               hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], hacc, 0, 0, 0);
               if (ks + RD < XKS) wf[ks + RD] = *(const v8bf*)(st + (ks + RD) * 1024);
               gelu_slice(ks, (i - 1) & 1);
-              if (ks >= VC_MLP_ISSUE0 && ks < VC_MLP_ISSUE0 + 6 * VC_MLP_ISSUE_STEP && (ks - VC_MLP_ISSUE0) % VC_MLP_ISSUE_STEP == 0 && do_issue)
+              if (ks >= VC_MLP_ISSUE0 && ks < VC_MLP_ISSUE0 + NA * VC_MLP_ISSUE_STEP && (ks - VC_MLP_ISSUE0) % VC_MLP_ISSUE_STEP == 0 && do_issue)
                 issue_piece(nc1, nc2, slot ^ 1, (ks - VC_MLP_ISSUE0) / VC_MLP_ISSUE_STEP);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -1592,8 +1599,9 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           for (int q = 0; q < 24; ++q) {
             oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
             if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
-            if (q >= VC_MLP_ISSUE0 && q < VC_MLP_ISSUE0 + 6 * VC_MLP_ISSUE_STEP && (q - VC_MLP_ISSUE0) % VC_MLP_ISSUE_STEP == 0 && do_issue)
-              issue_piece(nc1, nc2, slot ^ 1, (q - VC_MLP_ISSUE0) / VC_MLP_ISSUE_STEP);   // (see the A waves)
+            constexpr int BSTEP = NB <= 6 ? VC_MLP_ISSUE_STEP : 2;
+            if (q >= VC_MLP_ISSUE0 && q < VC_MLP_ISSUE0 + NB * BSTEP && (q - VC_MLP_ISSUE0) % BSTEP == 0 && do_issue)
+              issue_piece(nc1, nc2, slot ^ 1, (q - VC_MLP_ISSUE0) / BSTEP);   // (see the A waves)
           }
         }
 #ifdef VC_MLP_PRIO_B
