@@ -1599,7 +1599,10 @@ __global__ __launch_bounds__(512, 2) void mlp2_kernel(__bf16* __restrict__ X, co
           for (int q = 0; q < 24; ++q) {
             oacc[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], (q & 1) ? g_s1 : g_s0, oacc[q >> 1], 0, 0, 0);
             if (q + RD < 24) wf[q + RD] = *(const v8bf*)(st2 + (q + RD) * 1024);
-            constexpr int BSTEP = NB <= 6 ? VC_MLP_ISSUE_STEP : 2;
+#ifndef VC_MLP_BSTEP
+#define VC_MLP_BSTEP 2
+#endif
+            constexpr int BSTEP = NB <= 6 ? VC_MLP_ISSUE_STEP : VC_MLP_BSTEP;
             if (q >= VC_MLP_ISSUE0 && q < VC_MLP_ISSUE0 + NB * BSTEP && (q - VC_MLP_ISSUE0) % BSTEP == 0 && do_issue)
               issue_piece(nc1, nc2, slot ^ 1, (q - VC_MLP_ISSUE0) / BSTEP);   // (see the A waves)
           }
