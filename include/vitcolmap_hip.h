@@ -300,9 +300,12 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
  * [n_out] bf16, out [batch * height * width][n_out] bf16.  epilogue VC_EPI_BIAS or VC_EPI_GELU.  n_out % 256 == 0,
  * c_in % 64 == 0, kh * kw <= 16, the batch below 4 GiB, 16-byte aligned pointers.  A 3 x 3 pad-1 convolution is
  * (kh, kw, dy0, dx0) = (3, 3, -1, -1).
+ * out_parity: -1 = out as above.  2 i + j (0..3) = this call is parity class (i, j) of a stride-2 transposed convolution: row
+ * (b, y, x) is written to pixel (2 y + i, 2 x + j) of out [batch][2 height][2 width][n_out]; the four calls of a layer
+ * (taps (kh, kw, dy0, dx0) = (2, 2, i - 1, j - 1)) fill that tensor without an interleaving copy.
  */
 int vc_conv_taps_bf16(void* x, const void* weight, const void* bias, void* out, int batch, int height, int width, int c_in,
-                      int n_out, int kh, int kw, int dy0, int dx0, int epilogue, vc_stream_t stream);
+                      int n_out, int kh, int kw, int dy0, int dx0, int out_parity, int epilogue, vc_stream_t stream);
 
 /*
  * The same linear layer for k_in == 384 (ViT-S: attn.qkv, attn.proj, mlp.fc1), "x-stationary":

@@ -173,6 +173,9 @@ def test_xs_linear_matches_float32_reference(rows, N, epi, ln):
     (3, 17, 23, 128, 256, 2, 2, -1, -1, 0),      # one parity class of the transposed convolution (taps up / left)
     (3, 17, 23, 128, 256, 2, 2, 0, 0, 1),        # ... (taps down / right)
     (1, 5, 7, 64, 256, 1, 1, 0, 0, 0),           # 1 x 1: a plain GEMM, fewer rows than one tile
+    (1, 1, 3, 64, 256, 3, 3, -1, -1, 0),         # a one-row image: six of nine taps outside everywhere
+    (2, 2, 2, 128, 512, 2, 2, 0, 0, 1),          # images smaller than the tap window
+    (5, 9, 31, 192, 256, 3, 3, -1, -1, 1),       # 1395 rows: tiles straddle image boundaries, last tile ragged
     (2, 120, 160, 256, 256, 3, 3, -1, -1, 1)])   # the heads' resolution
 def test_conv_taps_matches_float32_convolution(B, H, W, C, N, kh, kw, dy0, dx0, epi):
     """vc_conv_taps_bf16 (implicit GEMM over a channels-last batch, zero outside the image) vs torch's float32 conv2d on the
@@ -197,6 +200,29 @@ def test_conv_taps_matches_float32_convolution(B, H, W, C, N, kh, kw, dy0, dx0, 
     err = (out - ref).abs()
     assert bool((err <= ref.abs() * 2 ** -7 + 2e-2).all()), (float(err.max()), int((err > ref.abs() * 2 ** -7 + 2e-2).sum()))
     assert float((out - ref).norm() / ref.norm()) < 4e-3
+
+
+def test_conv_taps_parity_classes_are_a_transposed_convolution():
+    """Four vc_conv_taps_bf16 calls with out_parity = 2 i + j and the class matrices of model/hip_heads.py fill the
+    [B][2H][2W][N] tensor that ConvTranspose2d(kernel 4, stride 2, padding 1) computes (float32 on the same bf16 data)."""
+    from vit_colmap_amd.model.hip_heads import deconv_class_matrices
+    from vit_colmap_amd.vit.hip_ops import conv_rows, conv_taps, EPI_BIAS
+
+    B, H, W, C, N = 3, 9, 13, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xr = conv_rows(B, H, W, C, "cuda")
+    xr.copy_(torch.randn(xr.shape, device="cuda", generator=g).to(torch.bfloat16))
+    wt = (torch.randn(C, N, 4, 4, device="cuda", generator=g) / (4 * C) ** 0.5).to(torch.bfloat16)       # ConvTranspose2d layout
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.full((B * 4 * H * W + 1, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    for m, i, j, dy0, dx0 in deconv_class_matrices(wt):
+        conv_taps(xr, m.contiguous(), b, B, H, W, 2, 2, dy0, dx0, EPI_BIAS, out=out, out_parity=2 * i + j)
+    assert bool((out[-1] == 7.0).all())                                                                 # nothing written past the tensor
+    img = xr[: B * H * W].float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv_transpose2d(img, wt.float(), b.float(), stride=2, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * 4 * H * W, N)
+    err = (out[:-1].float() - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -7 + 2e-2).all()), float(err.max())
 
 
 def test_patch_embed_gemm_matches_reference_and_padded_preprocess():

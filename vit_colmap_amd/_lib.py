@@ -59,7 +59,7 @@ SIGNATURES = {
     "vc_layernorm_drop_first_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vc_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "vc_conv_taps_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "vc_conv_taps_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "vc_linear_xs_weight_bytes": (c_size_t, [c_int, c_int]),
     "vc_linear_xs_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vc_linear_xs_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

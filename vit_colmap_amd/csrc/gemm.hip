@@ -238,11 +238,14 @@ constexpr int kAhead2 = 6;                // units issued ahead of the phase tha
 // pixel (y + cdy0 + t / ckw, x + cdx0 + t % ckw) of the same image, or the zero row when that pixel is outside it.  A K tile
 // (64 channels of one tap) is the same 1 KiB pieces as before — the tap only moves the scalar base, and a lane whose pixel
 // is outside points at the zero row instead (one v_cndmask per piece).  W [N][K] with k in the same (tap, channel) order.
+// cpar >= 0: the result is one parity class of a stride-2 transposed convolution — row (b, y, x) goes to pixel
+// (2y + (cpar >> 1), 2x + (cpar & 1)) of a [batch][2 cH][2 cW][N] output (the four classes interleave there, no copy).
 template <int EPI, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restrict__ X, const __bf16* __restrict__ W,
                                                          const __bf16* __restrict__ bias, const __bf16* __restrict__ res,
                                                          __bf16* __restrict__ out, int M, int N, int K, int n_tiles_n,
-                                                         int n_tiles, int cH, int cW, int cC, int ckw, int cdy0, int cdx0) {
+                                                         int n_tiles, int cH, int cW, int cC, int ckw, int cdy0, int cdx0,
+                                                         int cpar) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds2[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -301,17 +304,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
     const bool is_x = j == 0 || j == 3;
     const char* sb = is_x ? xbase + (size_t)t * (BK * 2) : wbase + (size_t)t * (BK * 2) + (j == 2 ? whalf : 0);
     int tap = 0;
-    uint32_t zoff = 0;                     // CONV: offset (from sb) of this lane's 16 bytes in the zero row
+    uint32_t zoff = 0, spos = 0;           // CONV: offset (from sb) of this lane's 16 bytes in the zero row; forward part of the tap shift
     if (CONV && is_x) {
       tap = t / tiles_per_tap;
       const long long shift = ((long long)(cdy0 + tap / ckw) * cW + (cdx0 + tap % ckw)) * cC * 2;   // bytes, may be negative
-      sb = xbase + shift + (long long)(t - tap * tiles_per_tap) * (BK * 2);
-      zoff = (uint32_t)((long long)M * cC * 2 - shift) + (uint32_t)pchunk * 16u;
+      // a backward shift moves the scalar base (the per-lane offsets are unsigned), a forward one is added per lane: the
+      // zero row (behind the batch) stays reachable from the base however small the batch is
+      const long long sneg = shift < 0 ? shift : 0;
+      spos = (uint32_t)(shift - sneg);
+      sb = xbase + sneg + (long long)(t - tap * tiles_per_tap) * (BK * 2);
+      zoff = (uint32_t)((long long)M * cC * 2 - sneg) + (uint32_t)pchunk * 16u;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       uint32_t vo = j == 0 ? voffx[0][i] : (j == 3 ? voffx[1][i] : voffw[i]);
-      if (CONV && is_x) vo = ((j == 0 ? vtaps[0][i] : vtaps[1][i]) >> tap) & 1u ? vo : zoff;
+      if (CONV && is_x) vo = ((j == 0 ? vtaps[0][i] : vtaps[1][i]) >> tap) & 1u ? vo + spos : zoff;
       const uint32_t dst = lds0 + (uint32_t)(t & 1) * kBuf2 + (uint32_t)j * kUnit2 + (uint32_t)(wave * 2 + i) * 1024u;
       uint32_t keep;
       asm volatile(
@@ -476,11 +483,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (CONV && cpar >= 0) {
+    // a lane's 16 rows are 8 pixels apart: one division for the first, then carries
+    int mm = m0 + wr * 128 + lrow;
+    int pb = mm / (cH * cW), py = (mm - pb * cH * cW) / cW, px = mm - pb * cH * cW - py * cW;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = 8 * i + lrow, m = m0 + wr * 128 + row;
-    const v4u32 o = *(const v4u32*)ep_at(row, lslot * 16);
-    if (m < M) *(v4u32*)(out + (size_t)m * N + col0 + lslot * 8) = o;
+    for (int i = 0; i < 16; ++i) {
+      const int row = 8 * i + lrow;
+      const v4u32 o = *(const v4u32*)ep_at(row, lslot * 16);
+      const size_t orow = ((size_t)pb * 2 * cH + 2 * py + (cpar >> 1)) * (2 * cW) + 2 * px + (cpar & 1);
+      if (mm < M) *(v4u32*)(out + orow * N + col0 + lslot * 8) = o;
+      mm += 8;
+      px += 8;
+      while (px >= cW) { px -= cW; if (++py == cH) { py = 0; ++pb; } }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 8 * i + lrow, m = m0 + wr * 128 + row;
+      const v4u32 o = *(const v4u32*)ep_at(row, lslot * 16);
+      if (m < M) *(v4u32*)(out + (size_t)m * N + col0 + lslot * 8) = o;
+    }
   }
   asm volatile("s_barrier" ::: "memory");   // every wave is past its last fragment read of this tile before the next tile's copies land
   }  // tiles of this workgroup
@@ -1756,13 +1779,13 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
     const dim3 grid((unsigned)(nt < cus ? nt : cus)), block(512);
     switch (epilogue) {
       case EPI_BIAS:
-        hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0);
+        hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0, -1);
         break;
       case EPI_GELU:
-        hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0);
+        hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0, -1);
         break;
       default:
-        hipLaunchKernelGGL((gemm256_kernel<EPI_RESIDUAL, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0);
+        hipLaunchKernelGGL((gemm256_kernel<EPI_RESIDUAL, false>), grid, block, smem, s, px, pw, pb, pr, po, rows, n_out, k_in, tiles_n, (int)nt, 0, 0, 0, 1, 0, 0, -1);
         break;
     }
     return vc::check_launch();
@@ -1787,10 +1810,11 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
 
 
 int vc_conv_taps_bf16(void* x, const void* weight, const void* bias, void* out, int batch, int height, int width, int c_in,
-                      int n_out, int kh, int kw, int dy0, int dx0, int epilogue, vc_stream_t stream) {
+                      int n_out, int kh, int kw, int dy0, int dx0, int out_parity, int epilogue, vc_stream_t stream) {
   if (!x || !weight || !bias || !out || batch < 0 || height <= 0 || width <= 0 || c_in <= 0 || n_out <= 0) return VC_ERR_INVALID_ARG;
   if (epilogue != EPI_BIAS && epilogue != EPI_GELU) return VC_ERR_INVALID_ARG;
   if (kh <= 0 || kw <= 0 || kh * kw > 16 || dy0 < -8 || dy0 > 8 || dx0 < -8 || dx0 > 8) return VC_ERR_INVALID_ARG;
+  if (out_parity < -1 || out_parity > 3) return VC_ERR_INVALID_ARG;
   if (n_out % G2N != 0 || c_in % BK != 0) return VC_ERR_UNSUPPORTED;
   if ((((uintptr_t)x) | ((uintptr_t)weight) | ((uintptr_t)bias) | ((uintptr_t)out)) % 16 != 0) return VC_ERR_INVALID_ARG;
   const long long rows = (long long)batch * height * width;
@@ -1818,10 +1842,10 @@ int vc_conv_taps_bf16(void* x, const void* weight, const void* bias, void* out, 
   __bf16* po = (__bf16*)out;
   if (epilogue == EPI_BIAS)
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, true>), grid, block, (size_t)G256_LDS, s, px, pw, pb, (const __bf16*)nullptr, po, (int)rows,
-                       n_out, k_total, tiles_n, (int)nt, height, width, c_in, kw, dy0, dx0);
+                       n_out, k_total, tiles_n, (int)nt, height, width, c_in, kw, dy0, dx0, out_parity);
   else
     hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, true>), grid, block, (size_t)G256_LDS, s, px, pw, pb, (const __bf16*)nullptr, po, (int)rows,
-                       n_out, k_total, tiles_n, (int)nt, height, width, c_in, kw, dy0, dx0);
+                       n_out, k_total, tiles_n, (int)nt, height, width, c_in, kw, dy0, dx0, out_parity);
   return vc::check_launch();
 }
 

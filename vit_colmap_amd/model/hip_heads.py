@@ -6,7 +6,7 @@ Everything stays channels-last: the backbone's token grid (B, hp * wp, C) IS an 
 reads and writes [pixels][channels] rows (one spare zero row behind each batch for taps outside the image).
   * ConvTranspose2d(4, stride 2, pad 1): output pixel (2y + i, 2x + j) only sees input pixels (y + i - 1 + ty, x + j - 1 + tx),
     ty, tx in {0, 1}, through kernel element (3 - 2 ty - i, 3 - 2 tx - j): four 2 x 2-tap products, one per parity (i, j), whose
-    results are interleaved (`deconv_class_matrices`);
+    results are interleaved by the kernel's epilogue (`out_parity`; weights: `deconv_class_matrices`);
   * Conv2d 3 x 3 pad 1 (+ the eval BatchNorm folded in by `fold_batchnorm`, + GELU): one 9-tap product with the GELU in
     the epilogue; the two heads' first convolutions (256 -> 64 and 256 -> 128) run as ONE product padded to 256 outputs;
   * the heads' last 1 x 1 convolutions (64 -> 4, 128 -> D) are two small library GEMMs on slices of that result.
@@ -84,11 +84,9 @@ class HipHeads:
         x[: B * H * W].copy_(tokens.reshape(B * H * W, c))
         for blk in self.blocks:
             rows, co = B * H * W, blk["c_out"]
-            parts = torch.empty((2, 2, B, H, W, co), dtype=torch.bfloat16, device=dev)
-            for m, i, j, dy0, dx0 in blk["classes"]:
-                ops.conv_taps(x, m, blk["deconv_bias"], B, H, W, 2, 2, dy0, dx0, ops.EPI_BIAS, out=parts[i, j].view(rows, co))
             up = ops.conv_rows(B, 2 * H, 2 * W, co, dev)
-            up[: 4 * rows].view(B, H, 2, W, 2, co).copy_(parts.permute(2, 3, 0, 4, 1, 5))     # interleave the four parities
+            for m, i, j, dy0, dx0 in blk["classes"]:                                           # each call writes its parity's pixels
+                ops.conv_taps(x, m, blk["deconv_bias"], B, H, W, 2, 2, dy0, dx0, ops.EPI_BIAS, out=up, out_parity=2 * i + j)
             H, W = 2 * H, 2 * W
             x = ops.conv_rows(B, H, W, co, dev)
             ops.conv_taps(up, blk["conv_w"], blk["conv_b"], B, H, W, 3, 3, -1, -1, ops.EPI_GELU, out=x)

@@ -83,10 +83,11 @@ def conv_rows(batch: int, height: int, width: int, channels: int, device) -> tor
 
 
 def conv_taps(x_rows: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, batch: int, height: int, width: int,
-              kh: int, kw: int, dy0: int, dx0: int, epilogue: int = EPI_BIAS, out=None) -> torch.Tensor:
+              kh: int, kw: int, dy0: int, dx0: int, epilogue: int = EPI_BIAS, out=None, out_parity: int = -1) -> torch.Tensor:
     """Convolution over a channels-last image batch on the 256 x 256 implicit-GEMM tile (vc_conv_taps_bf16):
     x_rows [batch * height * width + 1][c_in] (see conv_rows), weight [n_out][kh * kw * c_in] with k = (tap, channel),
-    out [batch * height * width (+ anything)][n_out].  A 3 x 3 pad-1 convolution is (kh, kw, dy0, dx0) = (3, 3, -1, -1)."""
+    out [batch * height * width (+ anything)][n_out].  A 3 x 3 pad-1 convolution is (kh, kw, dy0, dx0) = (3, 3, -1, -1).
+    out_parity = 2 i + j: the rows go to pixels (2y + i, 2x + j) of `out` [batch][2 height][2 width][n_out] (required then)."""
     rows = batch * height * width
     c_in = x_rows.shape[1]
     n = weight.shape[0]
@@ -94,11 +95,13 @@ def conv_taps(x_rows: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ba
     assert weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] == kh * kw * c_in
     assert bias.dtype == torch.bfloat16 and bias.numel() == n
     if out is None:
+        assert out_parity < 0
         out = torch.empty((rows, n), dtype=torch.bfloat16, device=x_rows.device)
-    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[-1] == n and out.numel() >= rows * n
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and out.shape[-1] == n
+    assert out.numel() >= (rows if out_parity < 0 else 4 * rows) * n
     lib = _lib.load()
     _lib.check(lib.vc_conv_taps_bf16(_lib.ptr(x_rows), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), batch, height, width,
-                                     c_in, n, kh, kw, dy0, dx0, epilogue, _lib.stream_ptr()), "vc_conv_taps_bf16")
+                                     c_in, n, kh, kw, dy0, dx0, out_parity, epilogue, _lib.stream_ptr()), "vc_conv_taps_bf16")
     return out
 
 
