@@ -65,6 +65,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16
 MFMA_INT8_PEAK_TOPS = 5000.0          # dense int8 = 2x bf16 per clock (MI355X_MICROARCH.md, Matrix cores)
 TRAFFIC_PROFILE = "profiles/r03_matcher_traffic.json"   # rocprofv3 --pmc passes of this command (tools/prof_r03.sh)
 STRONG_IMAGES = 200                   # north_star / configs[3]: the fixed set of the scaling experiment
+# Developer rehearsal of the N > 1 code path on a box with ONE GPU (VITCOLMAP_BENCH_REHEARSE=1): every rank uses cuda:0 and the
+# collectives go through gloo on host copies.  The line it prints says "rehearsal": true and is not a measurement.
+REHEARSE = os.environ.get("VITCOLMAP_BENCH_REHEARSE") == "1"
 
 
 def parse_args():
@@ -93,7 +96,7 @@ def start_ranks(args):
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not REHEARSE:
         print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); refusing to report fewer ranks "
               "than asked for", file=sys.stderr)
         sys.exit(2)
@@ -235,7 +238,11 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if REHEARSE:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()             # what was actually initialised
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -258,7 +265,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if REHEARSE else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -292,7 +299,10 @@ def main():
             d_loc, c_loc = res["desc_u8"], res["count"]
             if pad_c.numel():
                 d_loc, c_loc = torch.cat([d_loc, pad_d]), torch.cat([c_loc, pad_c])
-            desc, counts = vd.all_gather_descriptors(d_loc, c_loc)
+            if REHEARSE and world > 1:
+                desc, counts = (t.to(dev) for t in vd.all_gather_descriptors(d_loc.cpu(), c_loc.cpu()))
+            else:
+                desc, counts = vd.all_gather_descriptors(d_loc, c_loc)
             if timed:
                 ev[2].record()
             prepared = prepare_descriptors(desc, counts)
@@ -518,6 +528,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16 (ViT) / u8+i32 (matcher)",
             "data": "synthetic",
+            **({"rehearsal": True} if REHEARSE else {}),
             "config": {
                 "workload": workload,
                 "images_total": n_total, "images_rank0": n_local, "image_size": [W, H], "num_keypoints": K,
