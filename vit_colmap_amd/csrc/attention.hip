@@ -356,22 +356,48 @@ __global__ __launch_bounds__(256, (QT == 1 ? 3 : 2)) void attention_kernel(const
 #endif
 
   // ---- normalise and store: lane (query r, half hh) holds d = (i&3) + 8(i>>2) + 4hh + 32dt -------
+  // Stored from that layout (16 stores of 8 bytes per lane, 32 rows per instruction) the tail of a unit is bound by store
+  // issue.  Instead v_permlane32_swap gives every lane 16 consecutive d of its query (as in the GEMM epilogues), the wave
+  // turns its QT x 32 queries x 64 d through 4 KiB x QT of the K/V ring — idle once every wave is past its last key block —
+  // and writes whole rows: 8 queries x 128 contiguous bytes (one head's 64 d) per store instruction, 4 QT per lane.
+  typedef uint32_t v4u32a __attribute__((ext_vector_type(4)));
+  __syncthreads();
+  uint8_t* const stg = (uint8_t*)lds + wave * (QT * 4096);
+  auto stg_at = [&](int row, int slot16) { return stg + row * 128 + ((slot16 ^ ((row >> 1) & 7)) << 4); };
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
     const float inv = 1.0f / l_tot;
-    const int q_row = q_row0 + 32 * qt;
-    if (q_row < N) {
-      __bf16* op = out + ((size_t)b * N + q_row) * (size_t)H * kHD + (size_t)h * kHD;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt) {
+      uint32_t ep[8];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          v4bf o;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const v2bf lo = {(__bf16)(acc_o[qt][dt][4 * g4] * inv), (__bf16)(acc_o[qt][dt][4 * g4 + 1] * inv)};
+        const v2bf hi = {(__bf16)(acc_o[qt][dt][4 * g4 + 2] * inv), (__bf16)(acc_o[qt][dt][4 * g4 + 3] * inv)};
+        ep[2 * g4] = *(const uint32_t*)&lo;
+        ep[2 * g4 + 1] = *(const uint32_t*)&hi;
+      }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (__bf16)(acc_o[qt][dt][4 * g4 + j] * inv);
-          *(v4bf*)(op + 32 * dt + 8 * g4 + 4 * hh) = o;
-        }
+      for (int k = 0; k < 4; ++k) {       // groups (0, 2) and (1, 3) change hands: hh = 0 ends with d 0..15 of the block, hh = 1 with 16..31
+        const auto sw = __builtin_amdgcn_permlane32_swap(ep[k], ep[k + 4], false, false);
+        ep[k] = sw[0];
+        ep[k + 4] = sw[1];
+      }
+      const int row = 32 * qt + r;
+      *(v4u32a*)stg_at(row, 4 * dt + 2 * hh) = (v4u32a){ep[0], ep[1], ep[4], ep[5]};
+      *(v4u32a*)stg_at(row, 4 * dt + 2 * hh + 1) = (v4u32a){ep[2], ep[3], ep[6], ep[7]};
+    }
+  }
+  {
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int q_wave0 = q_base + wave * (kQW * QT);
+#pragma unroll
+    for (int i = 0; i < 4 * QT; ++i) {
+      const int row = 8 * i + lrow;
+      const v4u32a o = *(const v4u32a*)stg_at(row, lslot);
+      if (q_wave0 + row < N)
+        *(v4u32a*)(out + ((size_t)b * N + q_wave0 + row) * (size_t)H * kHD + (size_t)h * kHD + lslot * 8) = o;
     }
   }
 #ifdef VC_ATTN_STAMP
