@@ -463,6 +463,8 @@ def main():
                         "image) + heat-map selection; random weights; NOT part of `value`",
             }
             del tex, tframes
+        except Exception as e:  # noqa: BLE001 - an informational leg must not take the contract line down with it
+            trainable = {"error": f"{type(e).__name__}: {e}"}
         finally:
             sys.stdout = so
 
