@@ -1758,8 +1758,17 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
                *pr = (const __bf16*)residual_or_null;
   __bf16* po = (__bf16*)out;
   static const int tile256 = [] { const char* e = getenv("VITCOLMAP_GEMM_TILE"); return e ? atoi(e) : 256; }();   // developer A/B: 128
-  if (n_out % G2N == 0 && rows >= 4 * G2M && tile256 == 256) {
-    // wide layers with enough rows to fill the chip: one 256 x 256 tile per workgroup, one workgroup per CU
+  int cus256 = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus256, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus256 <= 0)
+      cus256 = 256;
+  }
+  // wide layers with enough 256 x 256 tiles to occupy at least half the CUs (one workgroup per CU); below that the 128 x 128
+  // tile, two workgroups per CU, fills the chip better (a single image of ViT-B is 18-72 large tiles)
+  static const int min_fill_pct = [] { const char* e = getenv("VITCOLMAP_GEMM256_MIN_FILL"); return e ? atoi(e) : 50; }();
+  if (n_out % G2N == 0 && tile256 == 256 &&
+      (long long)((rows + G2M - 1) / G2M) * (n_out / G2N) * 100 >= (long long)cus256 * min_fill_pct) {
     const int tiles_m = (rows + G2M - 1) / G2M, tiles_n = n_out / G2N;
     const long long nt = (long long)tiles_m * tiles_n;
     if (nt > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
@@ -1772,10 +1781,7 @@ int vc_linear_bf16(const void* x, const void* weight, const void* bias, const vo
           return r;
         }))
       return st;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
+    const int cus = cus256;
     const dim3 grid((unsigned)(nt < cus ? nt : cus)), block(512);
     switch (epilogue) {
       case EPI_BIAS:
