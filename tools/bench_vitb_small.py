@@ -5,7 +5,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vit_colmap_amd.features.vit_extractor import ViTExtractor
 so, sys.stdout = sys.stdout, open(os.devnull, "w")
-ex = ViTExtractor(model_name="dinov2_vitb14", num_keypoints=2048, descriptor_dim=128)
+ex = ViTExtractor(model_name=sys.argv[1] if len(sys.argv) > 1 else "dinov2_vitb14", num_keypoints=2048, descriptor_dim=128)
 sys.stdout = so
 for B in (1, 2, 4, 8, 16):
     frames = torch.randint(0, 255, (B, 480, 640, 3), dtype=torch.uint8, device="cuda")
