@@ -196,3 +196,19 @@ def test_hip_heads_match_the_library_convolutions():
         assert a[key].shape == b[key].shape, key
         rel = float((a[key].float() - b[key].float()).norm() / b[key].float().norm())
         assert rel < 2e-2, (key, rel)
+
+
+def test_hip_heads_split_batches_that_exceed_the_32_bit_offsets(monkeypatch):
+    """A batch whose x4 activation tensor would pass 4 GiB goes through vc_conv_taps_bf16 in chunks: forcing the chunk size
+    down to one image gives the same maps as the whole batch."""
+    from vit_colmap_amd.features.trainable_vit_extractor import TrainableViTExtractor
+    from vit_colmap_amd.model import hip_heads
+
+    ex = TrainableViTExtractor(model_name="dinov2_vits14", num_keypoints=50, device="cuda", precision="bf16", seed=8)
+    tokens = torch.randn(3, 8 * 11, 384, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)).to(torch.bfloat16)
+    with torch.inference_mode():
+        whole = ex.model._hip_heads(tokens, 8, 11, (28, 38))
+        monkeypatch.setattr(hip_heads, "MAX_ACTIVATION_BYTES", 16 * 8 * 11 * 512 * 2 * 1.5)      # room for one image
+        split = ex.model._hip_heads(tokens, 8, 11, (28, 38))
+    for key in whole:
+        assert whole[key].shape == split[key].shape and torch.equal(whole[key], split[key]), key

@@ -20,6 +20,9 @@ import torch.nn.functional as F
 from ..vit import hip_ops as ops
 
 
+MAX_ACTIVATION_BYTES = 3.2e9      # per activation tensor of one vc_conv_taps_bf16 call (32-bit offsets, margin for the tap shifts)
+
+
 def conv3x3_matrix(weight: torch.Tensor) -> torch.Tensor:
     """Conv2d weight [N][C][3][3] -> [N][(ky, kx, c)]: k order of vc_conv_taps_bf16 with (kh, kw, dy0, dx0) = (3, 3, -1, -1)."""
     n = weight.shape[0]
@@ -78,6 +81,13 @@ class HipHeads:
         tensors; descriptors and features are channels-last views)."""
         B, n_tok, c = tokens.shape
         assert n_tok == hp * wp and tokens.dtype == torch.bfloat16 and tokens.is_cuda
+        # vc_conv_taps_bf16 addresses a batch with 32-bit offsets (< 4 GiB per activation tensor): large images go through in
+        # batch chunks (1600 x 1200: 160 MB per image at the x4 grid, 20 images per chunk)
+        widest = max([c] + [blk["c_out"] for blk in self.blocks])
+        b_max = max(1, int(MAX_ACTIVATION_BYTES // (16 * hp * wp * widest * 2)))
+        if B > b_max:
+            parts = [self(tokens[i:i + b_max], hp, wp, target_size) for i in range(0, B, b_max)]
+            return {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
         dev = tokens.device
         H, W = hp, wp
         x = ops.conv_rows(B, H, W, c, dev)
