@@ -1,4 +1,5 @@
 """GPU tests of the fused ViT glue kernels against PyTorch's own ops on the same device."""
+import numpy as np
 import pytest
 import torch
 
@@ -200,6 +201,42 @@ def test_conv_taps_matches_float32_convolution(B, H, W, C, N, kh, kw, dy0, dx0, 
     err = (out - ref).abs()
     assert bool((err <= ref.abs() * 2 ** -7 + 2e-2).all()), (float(err.max()), int((err > ref.abs() * 2 ** -7 + 2e-2).sum()))
     assert float((out - ref).norm() / ref.norm()) < 4e-3
+
+
+def test_conv_taps_random_geometries():
+    """Seeded random geometries (image sizes down to one pixel, windows up to 3 x 4 anywhere within +-2 of the pixel, 64..320
+    channels, batches that end inside a tile) against a float32 restatement of the entry's definition."""
+    from vit_colmap_amd.vit.hip_ops import conv_rows, conv_taps
+
+    rng = np.random.RandomState(20240)
+    for case in range(14):
+        B, H, W = int(rng.randint(1, 5)), int(rng.randint(1, 24)), int(rng.randint(1, 24))
+        C, N = 64 * int(rng.randint(1, 6)), 256 * int(rng.randint(1, 3))
+        kh, kw = int(rng.randint(1, 4)), int(rng.randint(1, 5))
+        dy0, dx0 = int(rng.randint(-2, 1)), int(rng.randint(-2, 1))
+        epi = int(rng.randint(0, 2))
+        g = torch.Generator(device="cuda").manual_seed(1000 + case)
+        xr = conv_rows(B, H, W, C, "cuda")
+        xr.copy_(torch.randn(xr.shape, device="cuda", generator=g).to(torch.bfloat16))
+        k = kh * kw * C
+        w = (torch.randn(N, k, device="cuda", generator=g) / k ** 0.5).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+        out = conv_taps(xr, w, b, B, H, W, kh, kw, dy0, dx0, epi).float()
+        img = xr[: B * H * W].float().reshape(B, H, W, C)
+        ref = b.float().reshape(1, 1, 1, N).expand(B, H, W, N).clone()
+        for ty in range(kh):
+            for tx in range(kw):
+                dy, dx = dy0 + ty, dx0 + tx
+                ys, ye, xs, xe = max(0, -dy), min(H, H - dy), max(0, -dx), min(W, W - dx)
+                if ys >= ye or xs >= xe:
+                    continue
+                t = ty * kw + tx
+                ref[:, ys:ye, xs:xe] += img[:, ys + dy:ye + dy, xs + dx:xe + dx] @ w[:, t * C:(t + 1) * C].float().t()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        ref = ref.reshape(B * H * W, N)
+        err = (out - ref).abs()
+        assert bool((err <= ref.abs() * 2 ** -7 + 2e-2).all()), (case, (B, H, W, C, N, kh, kw, dy0, dx0, epi), float(err.max()))
 
 
 def test_conv_taps_parity_classes_are_a_transposed_convolution():
