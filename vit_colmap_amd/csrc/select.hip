@@ -259,7 +259,6 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
   float* tmp_score = (float*)(tmp_cell + kMaxCandidates);
   int* state = (int*)(tmp_score + kMaxCandidates);        // [kMaxCandidates] NMS: 0 open, 1 kept, 2 gone
   int* cell_rank = state + kMaxCandidates;                // [cells] rank of the candidate on a cell, or -1
-  __shared__ int s_flag;
   __shared__ int s_wave_tot[kSelThreads / 64];
 
   for (int i = tid; i < cells; i += nt) score[i] = score_g[(size_t)img * cells + i];
@@ -294,17 +293,37 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
   __syncthreads();
 
   // ---- more than target: keep the global top `target`, in order ----------------------------
+  // The candidate list is nbh * nbw runs of k entries, each run already in the total order (a bin's ranks; ties inside a run
+  // are in candidate-index order, which is what `before` breaks ties by).  The rank of an entry in the whole list is its
+  // position in its own run plus, per other run, the length of that run's prefix that comes before it — a binary search,
+  // not a pass over all K candidates.
+  int run_len = k, n_runs = nbh * nbw;
+  auto merged_rank = [&](int e) {
+    const float s = cand_score[e];
+    const int mine = e / run_len;
+    int rank = e - mine * run_len;
+    for (int q = 0; q < n_runs; ++q) {
+      if (q == mine) continue;
+      int lo = 0, hi = run_len;                  // first x in run q that does NOT come before e
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1, o = q * run_len + mid;
+        if (before(cand_score[o], o, s, e)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    return rank;
+  };
   if (K > target) {
     for (int e = tid; e < K; e += nt) {
-      const float s = cand_score[e];
-      int rank = 0;
-      for (int o = 0; o < K; ++o) rank += before(cand_score[o], o, s, e) ? 1 : 0;
-      if (rank < target) { tmp_cell[rank] = cand_cell[e]; tmp_score[rank] = s; }
+      const int rank = merged_rank(e);
+      if (rank < target) { tmp_cell[rank] = cand_cell[e]; tmp_score[rank] = cand_score[e]; }
     }
     __syncthreads();
     K = target;
     for (int e = tid; e < K; e += nt) { cand_cell[e] = tmp_cell[e]; cand_score[e] = tmp_score[e]; }
     __syncthreads();
+    run_len = K;                                 // one run now, in order
+    n_runs = 1;
   }
   if (dbg_cand_count) {
     for (int e = tid; e < K; e += nt) {
@@ -320,11 +339,9 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
   for (int i = tid; i < cells; i += nt) cell_rank[i] = -1;
   __syncthreads();
   for (int e = tid; e < K; e += nt) {
-    const float s = cand_score[e];
-    int rank = 0;
-    for (int o = 0; o < K; ++o) rank += before(cand_score[o], o, s, e) ? 1 : 0;
+    const int rank = merged_rank(e);
     tmp_cell[rank] = cand_cell[e];
-    tmp_score[rank] = s;
+    tmp_score[rank] = cand_score[e];
     state[rank] = 0;
   }
   __syncthreads();
@@ -334,9 +351,11 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
   const float r2 = nms_radius * nms_radius;
   // point r is kept iff no KEPT point of smaller rank lies at distance 0 < d < radius
   // (distances compare exactly on squared integers: sqrt is monotone and exact at 0)
+  // (one barrier per round: __syncthreads_or carries the "somebody decided" flag; a point reads its neighbours' states while
+  // others write theirs, which is harmless — a state changes once, 0 -> 1 or 0 -> 2, and a point decides only when every
+  // lower-ranked neighbour has, so it sees their final values whichever side of a write the read falls)
   for (int iter = 0; iter < K + 1; ++iter) {
-    if (tid == 0) s_flag = 0;
-    __syncthreads();
+    int progressed = 0;
     for (int r = tid; r < K; r += nt) {
       if (state[r] != 0) continue;
       const int cell = tmp_cell[r];
@@ -354,13 +373,10 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
           if (so == 1) dead = true;
           else if (so == 0) wait = true;
         }
-      if (dead) { state[r] = 2; s_flag = 1; }
-      else if (!wait) { state[r] = 1; s_flag = 1; }
+      if (dead) { state[r] = 2; progressed = 1; }
+      else if (!wait) { state[r] = 1; progressed = 1; }
     }
-    __syncthreads();
-    const int progressed = s_flag;
-    __syncthreads();
-    if (!progressed) break;
+    if (!__syncthreads_or(progressed)) break;
   }
   // ---- ordered compaction of the kept points (rank order = score order) ---------------------
   int base = 0;
