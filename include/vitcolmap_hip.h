@@ -154,8 +154,9 @@ int vc_score_map(const float* st, int n_images, int H, int W, int method, float*
  * score -> kept keypoints in score order: spatial binning with per-bin top-k (bin_size cells),
  * global top-`target`, greedy NMS at `nms_radius` cells (vit_extractor.py:404-543).
  * Total order everywhere: score descending, then position ascending.
- * out_yx [n_images][kmax][2] (y, x), out_score [n_images][kmax], out_count [n_images].
- * dbg_cand_* (all NULL or all non-NULL, same shapes): the candidate list before NMS.
+ * out_yx [n_images][kmax][2] (y, x), out_score [n_images][kmax], out_count [n_images]; the kernel writes every slot
+ * (zeros behind the kept points), so the buffers may be handed over uninitialised.
+ * dbg_cand_* (all NULL or all non-NULL, same shapes): the candidate list before NMS (slots behind it are left as they were).
  * Limits: target <= 4096, H*W*8 + 80 KiB <= 159 KiB, nms_radius <= 8; kmax >= min(target, candidates).
  */
 int vc_select_keypoints(const float* score, int n_images, int H, int W, int target, int bin_size,

@@ -401,7 +401,14 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
     base += tot;
     __syncthreads();
   }
-  if (tid == 0) out_count[img] = min(base, kmax);
+  // slots behind the kept points are zero (the host hands over uninitialised buffers: three fill launches per batch less)
+  const int total = min(base, kmax);
+  for (int p = total + tid; p < kmax; p += nt) {
+    out_yx[((size_t)img * kmax + p) * 2 + 0] = 0;
+    out_yx[((size_t)img * kmax + p) * 2 + 1] = 0;
+    out_score[(size_t)img * kmax + p] = 0.f;
+  }
+  if (tid == 0) out_count[img] = total;
 }
 
 // ---------------------------------------------------------------------------------------

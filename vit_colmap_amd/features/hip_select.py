@@ -57,9 +57,9 @@ def select_keypoints(score: torch.Tensor, target: int, bin_size: int = 16, nms_r
     if kmax is None:
         kmax = target
     dev = score.device
-    yx = torch.zeros((B, kmax, 2), dtype=torch.int32, device=dev)
-    sc = torch.zeros((B, kmax), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    yx = torch.empty((B, kmax, 2), dtype=torch.int32, device=dev)      # (the kernel zeroes the slots behind the kept points)
+    sc = torch.empty((B, kmax), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     dbg = (None, None, None)
     if debug_candidates:
         dbg = (torch.zeros_like(yx), torch.zeros_like(sc), torch.zeros_like(cnt))
