@@ -266,6 +266,8 @@ class ViTExtractor(BaseExtractor):
             cur.wait_event(done)
             for t in part.values():           # allocated on s, read on cur: the allocator must not hand the block back to s early
                 t.record_stream(cur)
+        if len(parts) == 1:                   # (torch.cat of one tensor is a copy: six of them per batch, 10 MB the largest)
+            return parts[0]
         return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
 
     @torch.inference_mode()
