@@ -158,9 +158,14 @@ class DinoV2(nn.Module):
         self._hip = None    # per-block XsLinear operands (prepare_hip), False when the architecture is not covered
 
     # -- weights --------------------------------------------------------------------------------
+    def load_state_dict(self, *args, **kwargs):
+        self._pos_cache = {}        # cached position embeddings / class-token rows belong to the old weights
+        return super().load_state_dict(*args, **kwargs)
+
     @torch.no_grad()
     def init_random(self, seed: int = 0):
         """Seeded random weights of trained-checkpoint scale (there is no network for the real ones)."""
+        self._pos_cache = {}
         g = torch.Generator().manual_seed(seed)
         for name, p in self.named_parameters():
             if name.endswith("gamma"):
@@ -230,10 +235,16 @@ class DinoV2(nn.Module):
                 raise ValueError("padded patches need prepare_hip() (ViT-S)")
             from . import hip_ops as ops
 
-            pos = self.interpolated_pos_embed(hp, wp).to(torch.bfloat16).contiguous()
+            ckey = ("hip", hp, wp, patches.device)
+            cached = self._pos_cache.get(ckey)
+            if cached is None:      # position embedding as the kernel wants it + the class-token row (cls + pos[0]), once per grid
+                pos = self.interpolated_pos_embed(hp, wp).to(torch.bfloat16).contiguous()
+                cached = (pos, (self.cls_token[0, 0].float() + pos[0, 0].float()).to(torch.bfloat16))
+                self._pos_cache[ckey] = cached
+            pos, cls_row = cached
             x = torch.empty((B, 1 + hp * wp, self.arch.dim), dtype=torch.bfloat16, device=patches.device)
             ops.patch_embed(patches, self._pe_w, self.patch_embed.proj.bias, pos, x)
-            x[:, 0] = (self.cls_token[0, 0].float() + pos[0, 0].float()).to(torch.bfloat16)
+            x[:, 0] = cls_row
             return self._blocks_hip(x)
         x = self.patch_embed.forward_patches(patches)
         x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.interpolated_pos_embed(hp, wp)
